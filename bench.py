@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the antialiased resample hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json metric / configs[1]): uint8 channels_last [B,3,438,906] -> [196,320] bilinear antialias,
+Pillow-exact arithmetic, B images per GPU resident in HBM before the timed region (B=1024 -> 1.22 GB in, far beyond
+the 256 MB Infinity Cache).  A "step" is one pass of the hot path over one such batch.  Images shard across ranks
+(weak scaling: fixed per-GPU batch); the only collective is the broadcast of the packed weight tables, outside
+the timed region.  Prints ONE JSON line on rank 0.
+
+roofline: dominant kernel's ALGORITHMIC bytes per launch (read input once + write output once = 1,378,644 B/image
+for this config) ÷ its average duration measured here with HIP events on the launch stream.
+cpu_baseline: the reference's own step_three separable C++ (oracle/_ref/ref_s3sep.so, built from /root/reference in
+the build container) timed on this box's host cores on a bounded sample; falls back to our C port (kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H_IN, W_IN, H_OUT, W_OUT, CH = 438, 906, 196, 320, 3
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ≈6290 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(seconds: float = 12.0):
+    """Reference CPU path on the host cores, bounded sample. Returns the cpu_baseline object."""
+    import oracle
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (1, CH, H_IN, W_IN), dtype=np.uint8)
+    x8 = torch.from_numpy(img)
+    mpix = H_IN * W_IN / 1e6
+    ref = None
+    try:
+        ref = oracle.load_ref("ref_s3sep")
+    except Exception:
+        ref = None
+    if ref is not None:
+        kind = "reference"
+
+        def run_u8():  # test.py:52-58,75: uint8 -> float -> op -> byte
+            return ref.forward(x8.float(), [H_OUT, W_OUT], False).byte()
+
+        xf = x8.float()
+
+        def run_f32():
+            return ref.forward(xf, [H_OUT, W_OUT], False)
+    else:
+        kind = "port"
+        xf_np = img.astype(np.float32)
+
+        def run_u8():
+            return oracle.harness_u8("linear", img, (H_OUT, W_OUT), nthreads=cores)
+
+        def run_f32():
+            return oracle.forward("linear", xf_np, (H_OUT, W_OUT), nthreads=cores)
+
+    def timeit(fn, budget):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget:
+                return dt / n, n
+
+    t_u8, n_u8 = timeit(run_u8, seconds * 0.5)
+    t_f32, n_f32 = timeit(run_f32, seconds * 0.5)
+    return {
+        "value": round(mpix / t_u8, 2), "unit": "Mpix/s", "cores": cores, "kind": kind,
+        "sample": (f"step_three -DUSE_SEPARABLE_KERNEL forward, [1,3,438,906]->[196,320] bilinear AA, uint8 via "
+                   f"float()/byte() as test.py does, {n_u8} calls in {seconds * 0.5:.0f}s, {cores} threads; "
+                   f"fp32-only: {mpix / t_f32:.1f} Mpix/s ({n_f32} calls)"),
+        "us_per_image": round(t_u8 * 1e6, 1), "f32_value": round(mpix / t_f32, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from interpolate_antialiasing_amd import _lib, sharding
+    from interpolate_antialiasing_amd import extension_interpolate as aa
+
+    # one collective: rank 0's packed weight tables -> everyone (outside the timed region)
+    sharding.prepare_tables(_lib.FILTER_LINEAR, _lib.TABLE_PIL, (H_IN, W_IN), (H_OUT, W_OUT), False, dev)
+
+    B = args.batch
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rank)
+    # channels_last storage [B,H,W,C] viewed as NCHW; generated on device, resident in HBM before timing
+    x = torch.randint(0, 256, (B, H_IN, W_IN, CH), dtype=torch.uint8, device=dev, generator=gen).permute(0, 3, 1, 2)
+    assert x.is_contiguous(memory_format=torch.channels_last)
+
+    def step():
+        return aa.linear_forward(x, [H_OUT, W_OUT], False)
+
+    for _ in range(args.warmup):
+        y = step()
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # on the current stream = the stream the shim hands to the C-ABI
+    for _ in range(args.steps):
+        y = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    wall = sharding.reduce_max_seconds(wall, dev)
+    total_images = sharding.reduce_sum_int(B * args.steps, dev)
+
+    if rank == 0:
+        # parity spot-check of what was just timed (image 0 of rank 0) against the oracle
+        import oracle
+
+        exp = oracle.pil_resize_u8("linear", x[:1].cpu().numpy(), (H_OUT, W_OUT))
+        max_abs_e = int(np.abs(y[:1].cpu().numpy().astype(int) - exp.astype(int)).max())
+        mpix_s = total_images * H_IN * W_IN / wall / 1e6
+        alg_bytes_img = CH * H_IN * W_IN + CH * H_OUT * W_OUT  # 1,378,644
+        kern_ms = ev_ms / args.steps  # one hot-path pass per step
+        achieved = alg_bytes_img * B / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mpix/s (input pixels) antialiased bilinear 438x906->196x320, uint8 channels_last, PIL-exact",
+            "value": round(mpix_s, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"uint8 channels_last [{B},3,438,906]->[196,320] bilinear antialias per GPU "
+                                   f"(BASELINE configs[1] batched), Pillow-exact integer arithmetic",
+                       "batch_per_gpu": B, "global_batch": B * world, "variant": variant,
+                       "parallelism": f"batch-shard x{world}"},
+            "max_abs_err_vs_oracle": max_abs_e,
+            "images_per_s": round(total_images / wall, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": variant, "kernel_ms": round(kern_ms, 4), "alg_bytes_per_launch": alg_bytes_img * B,
+                         "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/*
+ * aa_interp.h — C-ABI of libaa_interp.so: MI355X (gfx950) antialiased separable resample.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference binds the path through a
+ * pybind11 module (step_two_dot_two/extension_interpolate.cpp:46-51: linear_forward, nearest_forward,
+ * cubic_forward, linear_backward; step_three/extension_interpolate.cpp:17-19: forward); a maintainer
+ * replaces the bodies of those four wrappers (s2.2/extension_interpolate.cpp:7-42) with calls to the entry
+ * points below (INTEGRATION.md shows the stub).  Plain pointers and sizes only: no torch/ATen types.
+ *
+ * Conventions
+ *   - every pointer named *_dev is a DEVICE pointer (HBM); the caller allocates everything (outputs,
+ *     tables, workspace); nothing here allocates, frees or synchronises unless its comment says so;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is enqueued on it;
+ *   - tensors are 4-D (N,C,H,W) in one of two dense layouts: AA_NCHW (contiguous) or AA_NHWC
+ *     (torch.channels_last storage); the output uses the same layout as the input
+ *     (s2.2/aa_interpolation_impl.h:752 `suggest_memory_format`);
+ *   - return value: 0 on success, a negative aa_status otherwise (aa_strerror() gives the text).
+ */
+#ifndef AA_INTERP_H
+#define AA_INTERP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AA_INTERP_ABI_VERSION 1
+
+typedef void *aa_stream_t; /* hipStream_t */
+
+enum aa_status {
+  AA_OK = 0,
+  AA_ERR_BAD_FILTER = -1,    /* unknown filter id */
+  AA_ERR_BAD_DTYPE = -2,     /* dtype / table-kind combination not implemented ("... not implemented for 'X'") */
+  AA_ERR_BAD_LAYOUT = -3,
+  AA_ERR_BAD_SHAPE = -4,     /* non-positive sizes (upsample_2d_common_check), table/shape mismatch */
+  AA_ERR_NULL = -5,
+  AA_ERR_WORKSPACE = -6,     /* workspace smaller than aa_workspace_bytes() */
+  AA_ERR_KSIZE = -7,         /* ksize beyond what the kernels support */
+  AA_ERR_HIP = -8,           /* a HIP runtime call failed (launch error) */
+  AA_ERR_NO_DEVICE = -9
+};
+
+/* Filters: s2.2/aa_interpolation_impl.h:292-300 (triangle), :410-424 (Keys cubic a=-0.5), :367-372 (box;
+ * the reference binds it as "nearest_forward": "it's not nearest but box", extension_interpolate.cpp:48). */
+enum aa_filter { AA_FILTER_LINEAR = 0, AA_FILTER_CUBIC = 1, AA_FILTER_BOX = 2 };
+
+/* Element type of the image tensors. */
+enum aa_dtype { AA_U8 = 0, AA_F32 = 1, AA_F64 = 2 };
+
+enum aa_layout { AA_NCHW = 0, AA_NHWC = 1 };
+
+/* Arithmetic a weight table is built in (replaces HelperInterpBase::_compute_indices_weights_aa,
+ * s2.2/aa_interpolation_impl.h:195-281):
+ *   AA_TABLE_F32   the reference's scalar_t=float promotions, float weights   (f32 images; u8 "harness" mode)
+ *   AA_TABLE_F64   scalar_t=double                                            (f64 images)
+ *   AA_TABLE_PIL   Pillow's precompute_coeffs + normalize_coeffs_8bpc: double coefficients, int32 weights in
+ *                  22-bit fixed point (u8 images, bit-exact with PIL.Image.resize; SURVEY §8 a-U)         */
+enum aa_table_kind { AA_TABLE_PIL = 0, AA_TABLE_F32 = 1, AA_TABLE_F64 = 2 };
+
+/* ---- packed weight table (one flat device buffer = one RCCL broadcast payload) -------------------------
+ *   [ aa_table_header : 64 B ][ int32 xmin[out] ][ int32 xsize[out] ][ pad to 16 B ][ weight w[out*ksize] ]
+ * weight = float (F32), double (F64) or int32 (PIL).  Rows are zero-padded from xsize to ksize (s2.2:276-278). */
+typedef struct aa_table_header {
+  int32_t magic;         /* 'AATB' 0x42544141 */
+  int32_t filter;        /* aa_filter */
+  int32_t kind;          /* aa_table_kind */
+  int32_t in_size;
+  int32_t out_size;
+  int32_t ksize;         /* row pitch of w, = (int)ceilf(support)*2+1 (s2.2:210) */
+  int32_t align_corners;
+  int32_t max_taps;      /* max_i xsize[i], filled by the device kernel */
+  int32_t transposed;    /* 1 for an adjoint (backward) table built by aa_table_transpose */
+  int32_t reserved[7];
+} aa_table_header;
+
+/* Host-side description of one axis handed to the resample calls. */
+typedef struct aa_axis {
+  const void *table_dev; /* packed table in HBM */
+  int32_t in_size;
+  int32_t out_size;
+  int32_t ksize;
+  int32_t max_taps;      /* from aa_table_query(); 0 = unknown (kernels then use ksize) */
+  int32_t kind;          /* aa_table_kind */
+  int32_t filter;        /* aa_filter */
+} aa_axis;
+
+/* Version / diagnostics. */
+int aa_abi_version(void);
+const char *aa_strerror(int status);
+/* Number of visible HIP devices (0 on a CPU-only host; never throws). */
+int aa_device_count(void);
+
+/* ksize for (filter, kind, in, out): host arithmetic with the reference's promotions (s2.2:207-210), or
+ * Pillow's for AA_TABLE_PIL.  scale<=0: scale derived from sizes (area_pixel_compute_scale, call site
+ * s2.2:314-315).  Returns ksize (>0) or a negative aa_status. */
+int aa_table_ksize(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale);
+/* Bytes of the packed table for (kind, out_size, ksize). */
+size_t aa_table_bytes(int kind, int64_t out_size, int ksize);
+
+/* Build a packed table ON DEVICE (one thread per output index).  Asynchronous on `stream`. */
+int aa_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
+                   void *table_dev, size_t table_bytes, aa_stream_t stream);
+
+/* Upper bound for the ksize of the adjoint of a table (host arithmetic only). */
+int aa_table_transposed_ksize(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale);
+/* Build the adjoint (gather-form) table of `table_dev` on device: for every INPUT index x, the contiguous
+ * range of outputs whose window holds x and their weights.  The result is a packed table whose in_size/out_size
+ * are swapped, usable with aa_resample_fwd to compute the TRUE adjoint (what test.py:387-398 asks for; the
+ * reference's own backward header is non-AA).  F32/F64 kinds only.  Asynchronous. */
+int aa_table_transpose(const void *table_dev, void *tr_table_dev, size_t tr_table_bytes, int tr_ksize,
+                       aa_stream_t stream);
+
+/* Copy a table header back to the host.  SYNCHRONISES `stream` (one-off, at table-build time, never in the
+ * per-call path). */
+int aa_table_query(const void *table_dev, aa_table_header *host_header, aa_stream_t stream);
+
+/* Workspace (bytes) the forward needs for this problem; 0 when the fused single-launch path applies. */
+size_t aa_workspace_bytes(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, int64_t oH, int64_t oW,
+                          const aa_axis *ax_h, const aa_axis *ax_w);
+
+/* Forward: replaces ti_upsample_{bilinear,bicubic,nearest}2d_cpu + the separable driver + both passes
+ * (s2.2/aa_interpolation_impl.h:731-807, :628-683, :536-625, :131-187, :29-120).
+ *   in_dev  [N,C,H,W]  dtype/layout as given          out_dev [N,C,oH,oW] same dtype/layout
+ *   ax_w: table for W -> oW (first pass, like the reference and PIL); ax_h: H -> oH (second pass).
+ * Table kind selects the arithmetic: F32/F64 tables with f32/f64 images (bit-comparable with the reference's
+ * CPU path: separately rounded product and sum, taps in order); u8 images with AA_TABLE_PIL tables give
+ * Pillow's integer result; u8 images with AA_TABLE_F32 tables give the reference harness semantics
+ * (test.py:52-58,72,75: float(), fp32 op, bicubic clamp, truncating byte()).
+ * Empty batch (N==0) is allowed (s2.2:747-750).  Asynchronous on `stream`. */
+int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
+                    int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
+                    aa_stream_t stream);
+
+/* Backward (true adjoint): grad_in[N,C,H,W] = H^T V^T grad_out[N,C,oH,oW], F32/F64 only.  Replaces
+ * ti_upsample_bilinear2d_backward_cpu (s2.2/aa_interpolation_backward_impl.h:185-219) in API shape.
+ * tr_h / tr_w are TRANSPOSED tables from aa_table_transpose (gather form: deterministic, no atomics, no zero fill). */
+int aa_resample_bwd(const void *grad_out_dev, void *grad_in_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
+                    int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *tr_h, const aa_axis *tr_w,
+                    aa_stream_t stream);
+/* Scatter form of the same adjoint with fp32/fp64 atomics straight from the FORWARD tables (BASELINE config 5
+ * names it); grad_in is zero-filled first by the call.  Results agree with aa_resample_bwd to rounding only. */
+int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *workspace_dev, size_t workspace_bytes,
+                           int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h,
+                           const aa_axis *ax_w, aa_stream_t stream);
+size_t aa_workspace_bytes_bwd(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, int64_t oH, int64_t oW);
+
+/* Name of the kernel variant the last aa_resample_fwd on this thread dispatched to (for tests/bench). */
+const char *aa_last_variant(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AA_INTERP_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libaa_interp.so (the C-ABI declared in include/aa_interp.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C interpolate_antialiasing_amd/csrc``.
+There is NO fallback: if the shared object is missing, loading fails loudly, and every op in this package
+needs it (the CPU oracle under oracle/ is test infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libaa_interp.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "aa_interp.h")
+
+# enums (include/aa_interp.h)
+AA_OK = 0
+FILTER_LINEAR, FILTER_CUBIC, FILTER_BOX = 0, 1, 2
+U8, F32, F64 = 0, 1, 2
+NCHW, NHWC = 0, 1
+TABLE_PIL, TABLE_F32, TABLE_F64 = 0, 1, 2
+ERR_BAD_DTYPE = -2
+
+# every symbol include/aa_interp.h declares (tests check the .so exports exactly these)
+EXPORTS = (
+    "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build",
+    "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_workspace_bytes", "aa_resample_fwd",
+    "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_last_variant",
+)
+
+
+class TableHeader(ctypes.Structure):
+    _fields_ = [
+        ("magic", ctypes.c_int32), ("filter", ctypes.c_int32), ("kind", ctypes.c_int32), ("in_size", ctypes.c_int32),
+        ("out_size", ctypes.c_int32), ("ksize", ctypes.c_int32), ("align_corners", ctypes.c_int32),
+        ("max_taps", ctypes.c_int32), ("transposed", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7),
+    ]
+
+
+class Axis(ctypes.Structure):
+    _fields_ = [
+        ("table_dev", ctypes.c_void_p), ("in_size", ctypes.c_int32), ("out_size", ctypes.c_int32),
+        ("ksize", ctypes.c_int32), ("max_taps", ctypes.c_int32), ("kind", ctypes.c_int32), ("filter", ctypes.c_int32),
+    ]
+
+
+class AAInterpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libaa_interp.so, declaring every prototype.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AAInterpError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C interpolate_antialiasing_amd/csrc`). "
+            "There is no CPU fallback."
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    i32, i64, dbl, vp, sz = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+    ax = ctypes.POINTER(Axis)
+    L.aa_abi_version.restype = i32
+    L.aa_strerror.argtypes = [i32]
+    L.aa_strerror.restype = ctypes.c_char_p
+    L.aa_device_count.restype = i32
+    L.aa_table_ksize.argtypes = [i32, i32, i64, i64, i32, dbl]
+    L.aa_table_ksize.restype = i32
+    L.aa_table_bytes.argtypes = [i32, i64, i32]
+    L.aa_table_bytes.restype = sz
+    L.aa_table_build.argtypes = [i32, i32, i64, i64, i32, dbl, vp, sz, vp]
+    L.aa_table_build.restype = i32
+    L.aa_table_transposed_ksize.argtypes = [i32, i32, i64, i64, i32, dbl]
+    L.aa_table_transposed_ksize.restype = i32
+    L.aa_table_transpose.argtypes = [vp, vp, sz, i32, vp]
+    L.aa_table_transpose.restype = i32
+    L.aa_table_query.argtypes = [vp, ctypes.POINTER(TableHeader), vp]
+    L.aa_table_query.restype = i32
+    L.aa_workspace_bytes.argtypes = [i32, i32, i64, i64, i64, i64, i64, i64, ax, ax]
+    L.aa_workspace_bytes.restype = sz
+    L.aa_resample_fwd.argtypes = [vp, vp, vp, sz, i32, i32, i64, i64, i64, i64, ax, ax, vp]
+    L.aa_resample_fwd.restype = i32
+    L.aa_resample_bwd.argtypes = [vp, vp, vp, sz, i32, i32, i64, i64, i64, i64, ax, ax, vp]
+    L.aa_resample_bwd.restype = i32
+    L.aa_resample_bwd_atomic.argtypes = [vp, vp, vp, sz, i32, i32, i64, i64, i64, i64, ax, ax, vp]
+    L.aa_resample_bwd_atomic.restype = i32
+    L.aa_workspace_bytes_bwd.argtypes = [i32, i32, i64, i64, i64, i64, i64, i64]
+    L.aa_workspace_bytes_bwd.restype = sz
+    L.aa_last_variant.restype = ctypes.c_char_p
+    if L.aa_abi_version() != 1:
+        raise AAInterpError("libaa_interp.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def strerror(rc: int) -> str:
+    return load().aa_strerror(rc).decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc < 0:
+        msg = f"{what}: {strerror(rc)} (aa_status {rc})" if what else f"{strerror(rc)} (aa_status {rc})"
+        if rc == ERR_BAD_DTYPE:
+            raise NotImplementedError(msg)
+        raise AAInterpError(msg)
+
+
+def last_variant() -> str:
+    return load().aa_last_variant().decode()

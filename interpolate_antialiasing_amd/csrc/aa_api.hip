@@ -1,0 +1,262 @@
+// aa_api.hip — the C-ABI (include/aa_interp.h): argument checks, host-side ksize arithmetic, dispatch.
+// No allocation, no synchronisation (except aa_table_query, documented), no torch types.
+
+#include <math.h>
+#include <string.h>
+
+#include "aa_common.h"
+
+namespace {
+
+thread_local const char *g_last_variant = "none";
+
+int interp_size_of(int filter) {
+  switch (filter) {
+    case AA_FILTER_LINEAR: return 2;  // s2.2/aa_interpolation_impl.h:287
+    case AA_FILTER_CUBIC: return 4;   // :377
+    case AA_FILTER_BOX: return 1;     // :333
+    default: return -1;
+  }
+}
+
+// ATen area_pixel_compute_scale<scalar_t> (UpSample.h; call site s2.2:314-315). scale<=0: not given.
+double scale_for(int kind, int64_t in_size, int64_t out_size, int align_corners, double scale_opt) {
+  if (kind == AA_TABLE_F32) {
+    if (align_corners) return out_size > 1 ? (double)((float)(in_size - 1) / (float)(out_size - 1)) : 0.0;
+    if (scale_opt > 0.) return (double)(float)(1.0 / scale_opt);
+    return (double)((float)in_size / (float)out_size);
+  }
+  if (align_corners) return out_size > 1 ? (double)(in_size - 1) / (double)(out_size - 1) : 0.0;
+  if (scale_opt > 0.) return 1.0 / scale_opt;
+  return (double)in_size / (double)out_size;
+}
+
+int ksize_for(int filter, int kind, double scale) {
+  const int interp_size = interp_size_of(filter);
+  if (kind == AA_TABLE_PIL) {
+    // Pillow precompute_coeffs: support = filter.support * max(scale,1); ksize = (int)ceil(support)*2+1
+    const double fs = filter == AA_FILTER_LINEAR ? 1.0 : (filter == AA_FILTER_CUBIC ? 2.0 : 0.5);
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    return (int)ceil(fs * filterscale) * 2 + 1;
+  }
+  if (kind == AA_TABLE_F32) {
+    const float s = (float)scale;
+    const float support = (s >= 1.0) ? (float)((interp_size * 0.5) * s) : (float)(interp_size * 0.5);  // s2.2:208-209
+    return (int)ceilf(support) * 2 + 1;                                                                  // s2.2:210
+  }
+  const double support = (scale >= 1.0) ? (interp_size * 0.5) * scale : interp_size * 0.5;
+  return (int)ceilf((float)support) * 2 + 1;  // the reference calls ceilf() for double too
+}
+
+bool valid_kind(int kind) { return kind == AA_TABLE_PIL || kind == AA_TABLE_F32 || kind == AA_TABLE_F64; }
+
+int check_axis(const aa_axis *a, int64_t in_size) {
+  if (!a || !a->table_dev) return AA_ERR_NULL;
+  if (a->in_size != in_size || a->out_size <= 0 || a->ksize <= 0) return AA_ERR_BAD_SHAPE;
+  if (a->ksize > AA_MAX_KSIZE) return AA_ERR_KSIZE;
+  if (!valid_kind(a->kind)) return AA_ERR_BAD_DTYPE;
+  return AA_OK;
+}
+
+int check_dtype_kind(int dtype, int kh, int kw) {
+  if (kh != kw) return AA_ERR_BAD_DTYPE;
+  if (dtype == AA_F32 && kh == AA_TABLE_F32) return AA_OK;
+  if (dtype == AA_F64 && kh == AA_TABLE_F64) return AA_OK;
+  if (dtype == AA_U8 && (kh == AA_TABLE_PIL || kh == AA_TABLE_F32)) return AA_OK;
+  return AA_ERR_BAD_DTYPE;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aa_abi_version(void) { return AA_INTERP_ABI_VERSION; }
+
+const char *aa_strerror(int status) {
+  switch (status) {
+    case AA_OK: return "ok";
+    case AA_ERR_BAD_FILTER: return "unknown filter";
+    case AA_ERR_BAD_DTYPE: return "dtype / weight-table kind combination not implemented";
+    case AA_ERR_BAD_LAYOUT: return "layout must be AA_NCHW or AA_NHWC";
+    case AA_ERR_BAD_SHAPE: return "Input and output sizes should be greater than 0 and match the weight tables";
+    case AA_ERR_NULL: return "null pointer argument";
+    case AA_ERR_WORKSPACE: return "workspace smaller than aa_workspace_bytes()";
+    case AA_ERR_KSIZE: return "filter support (ksize) beyond the supported maximum";
+    case AA_ERR_HIP: return "HIP kernel launch failed";
+    case AA_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown aa_status";
+  }
+}
+
+int aa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int aa_table_ksize(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale) {
+  if (interp_size_of(filter) < 0) return AA_ERR_BAD_FILTER;
+  if (!valid_kind(kind)) return AA_ERR_BAD_DTYPE;
+  if (in_size <= 0 || out_size <= 0 || in_size > INT32_MAX / 4 || out_size > INT32_MAX / 4) return AA_ERR_BAD_SHAPE;
+  if (kind == AA_TABLE_PIL && (align_corners || scale > 0.)) return AA_ERR_BAD_DTYPE;  // Pillow has neither
+  const int k = ksize_for(filter, kind, scale_for(kind, in_size, out_size, align_corners, scale));
+  if (k > AA_MAX_KSIZE) return AA_ERR_KSIZE;
+  return k;
+}
+
+size_t aa_table_bytes(int kind, int64_t out_size, int ksize) {
+  if (!valid_kind(kind) || out_size <= 0 || ksize <= 0) return 0;
+  return aa_table_total_bytes(kind, out_size, ksize);
+}
+
+int aa_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
+                   void *table_dev, size_t table_bytes, aa_stream_t stream) {
+  const int k = aa_table_ksize(filter, kind, in_size, out_size, align_corners, scale);
+  if (k < 0) return k;
+  if (!table_dev) return AA_ERR_NULL;
+  if (table_bytes < aa_table_total_bytes(kind, out_size, k)) return AA_ERR_WORKSPACE;
+  return aa_launch_table_build(filter, kind, in_size, out_size, align_corners,
+                               scale_for(kind, in_size, out_size, align_corners, scale), k, table_dev,
+                               (hipStream_t)stream);
+}
+
+int aa_table_transposed_ksize(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale) {
+  const int k = aa_table_ksize(filter, kind, in_size, out_size, align_corners, scale);
+  if (k < 0) return k;
+  if (kind == AA_TABLE_PIL) return AA_ERR_BAD_DTYPE;
+  // an input index x lies in the windows of the outputs whose centre is within +-support of it: about
+  // 2*support/scale of them (= interp_size when down-scaling, interp_size/scale when up-scaling); +3 covers the
+  // integer rounding of both window ends.
+  const double s = scale_for(kind, in_size, out_size, align_corners, scale);
+  const int interp_size = interp_size_of(filter);
+  const double support = (s >= 1.0) ? interp_size * 0.5 * s : interp_size * 0.5;
+  double cover = (s > 0.) ? (2.0 * support + 1.0) / s : (double)out_size;
+  int tk = (int)ceil(cover) + 3;
+  if (tk > out_size) tk = (int)out_size;
+  if (tk < 1) tk = 1;
+  if (tk > AA_MAX_KSIZE) return AA_ERR_KSIZE;
+  return tk;
+}
+
+int aa_table_query(const void *table_dev, aa_table_header *host_header, aa_stream_t stream) {
+  if (!table_dev || !host_header) return AA_ERR_NULL;
+  if (hipMemcpyAsync(host_header, table_dev, sizeof(aa_table_header), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+    return AA_ERR_HIP;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return AA_ERR_HIP;
+  if (host_header->magic != AA_TABLE_MAGIC) return AA_ERR_BAD_SHAPE;
+  return AA_OK;
+}
+
+int aa_table_transpose(const void *table_dev, void *tr_table_dev, size_t tr_table_bytes, int tr_ksize,
+                       aa_stream_t stream) {
+  if (!table_dev || !tr_table_dev) return AA_ERR_NULL;
+  aa_table_header h;
+  int rc = aa_table_query(table_dev, &h, stream);  // table-build time only
+  if (rc != AA_OK) return rc;
+  if (h.kind == AA_TABLE_PIL) return AA_ERR_BAD_DTYPE;
+  if (tr_ksize <= 0 || tr_ksize > AA_MAX_KSIZE) return AA_ERR_KSIZE;
+  if (tr_table_bytes < aa_table_total_bytes(h.kind, h.in_size, tr_ksize)) return AA_ERR_WORKSPACE;
+  return aa_launch_table_transpose(h, table_dev, tr_table_dev, tr_ksize, (hipStream_t)stream);
+}
+
+size_t aa_workspace_bytes(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, int64_t oH, int64_t oW,
+                          const aa_axis *ax_h, const aa_axis *ax_w) {
+  (void)oH;
+  if (!ax_h || !ax_w || N <= 0) return 0;
+  if (aa_fused_u8_nhwc_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
+  if (aa_fused_float_nchw_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
+  return aa_generic_workspace_bytes(dtype, ax_w->kind, N, C, H, oW);
+}
+
+int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
+                    int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
+                    aa_stream_t stream) {
+  if (dtype != AA_U8 && dtype != AA_F32 && dtype != AA_F64) return AA_ERR_BAD_DTYPE;
+  if (layout != AA_NCHW && layout != AA_NHWC) return AA_ERR_BAD_LAYOUT;
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0) return AA_ERR_BAD_SHAPE;
+  int rc = check_axis(ax_h, H);
+  if (rc != AA_OK) return rc;
+  rc = check_axis(ax_w, W);
+  if (rc != AA_OK) return rc;
+  rc = check_dtype_kind(dtype, ax_h->kind, ax_w->kind);
+  if (rc != AA_OK) return rc;
+  if (N == 0) {  // empty batch is allowed (s2.2:747-750)
+    g_last_variant = "empty";
+    return AA_OK;
+  }
+  if (!in_dev || !out_dev) return AA_ERR_NULL;
+
+  AAProblem p;
+  p.in = in_dev; p.out = out_dev; p.ws = workspace_dev; p.ws_bytes = workspace_bytes;
+  p.dtype = dtype; p.layout = layout;
+  p.N = N; p.C = C; p.H = H; p.W = W; p.oH = ax_h->out_size; p.oW = ax_w->out_size;
+  p.ah = *ax_h; p.aw = *ax_w;
+  p.stream = (hipStream_t)stream;
+
+  const char *variant = "none";
+  rc = aa_try_fused_u8_nhwc(p, &variant);
+  if (rc == 0) rc = aa_try_fused_float_nchw(p, &variant);
+  if (rc < 0) return rc;
+  if (rc == 1) {
+    g_last_variant = variant;
+    return AA_OK;
+  }
+  const size_t need = aa_generic_workspace_bytes(dtype, ax_w->kind, N, C, H, p.oW);
+  if (!workspace_dev || workspace_bytes < need) return AA_ERR_WORKSPACE;
+  rc = aa_launch_generic_fwd(p, &variant);
+  if (rc == AA_OK) g_last_variant = variant;
+  return rc;
+}
+
+size_t aa_workspace_bytes_bwd(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, int64_t oH, int64_t oW) {
+  (void)layout; (void)H; (void)oW;
+  if (N <= 0) return 0;
+  // gather form: intermediate [N,C,oH,W]; scatter form: intermediate [N,C,H,oW]; size for the larger
+  const size_t elem = dtype == AA_F64 ? 8 : 4;
+  const size_t a = (size_t)N * C * oH * W, b = (size_t)N * C * H * oW;
+  return aa_align16((a > b ? a : b) * elem);
+}
+
+int aa_resample_bwd(const void *grad_out_dev, void *grad_in_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
+                    int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *tr_h, const aa_axis *tr_w,
+                    aa_stream_t stream) {
+  if (dtype != AA_F32 && dtype != AA_F64) return AA_ERR_BAD_DTYPE;
+  if (!tr_h || !tr_w) return AA_ERR_NULL;
+  // The adjoint in gather form IS a forward resample of grad_out [N,C,oH,oW] with the transposed tables
+  // (tr_w: oW -> W, tr_h: oH -> H); the two 1-D adjoints act on different axes and commute.
+  if (tr_h->out_size != H || tr_w->out_size != W) return AA_ERR_BAD_SHAPE;
+  return aa_resample_fwd(grad_out_dev, grad_in_dev, workspace_dev, workspace_bytes, dtype, layout, N, C, tr_h->in_size,
+                         tr_w->in_size, tr_h, tr_w, stream);
+}
+
+int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *workspace_dev, size_t workspace_bytes,
+                           int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h,
+                           const aa_axis *ax_w, aa_stream_t stream) {
+  if (dtype != AA_F32 && dtype != AA_F64) return AA_ERR_BAD_DTYPE;
+  if (layout != AA_NCHW && layout != AA_NHWC) return AA_ERR_BAD_LAYOUT;
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0) return AA_ERR_BAD_SHAPE;
+  int rc = check_axis(ax_h, H);
+  if (rc != AA_OK) return rc;
+  rc = check_axis(ax_w, W);
+  if (rc != AA_OK) return rc;
+  rc = check_dtype_kind(dtype, ax_h->kind, ax_w->kind);
+  if (rc != AA_OK) return rc;
+  if (N == 0) return AA_OK;
+  if (!grad_out_dev || !grad_in_dev) return AA_ERR_NULL;
+  const size_t need = aa_workspace_bytes_bwd(dtype, layout, N, C, H, W, ax_h->out_size, ax_w->out_size);
+  if (!workspace_dev || workspace_bytes < need) return AA_ERR_WORKSPACE;
+  AAProblem p;
+  p.in = grad_out_dev; p.out = grad_in_dev; p.ws = workspace_dev; p.ws_bytes = workspace_bytes;
+  p.dtype = dtype; p.layout = layout;
+  p.N = N; p.C = C; p.H = H; p.W = W; p.oH = ax_h->out_size; p.oW = ax_w->out_size;
+  p.ah = *ax_h; p.aw = *ax_w;
+  p.stream = (hipStream_t)stream;
+  return aa_launch_bwd_atomic(p);
+}
+
+const char *aa_last_variant(void) { return g_last_variant; }
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// aa_common.h — shared host/device definitions for libaa_interp.so (gfx950 only; no CUDA paths).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aa_interp.h"
+
+#define AA_TABLE_MAGIC 0x42544141
+#define AA_MAX_KSIZE 4096  // generic kernels loop over taps, so this only bounds sanity
+
+// ---- packed table views --------------------------------------------------------------------------------
+__host__ __device__ inline size_t aa_align16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t aa_weight_elem_bytes(int kind) { return kind == AA_TABLE_F64 ? 8 : 4; }
+__host__ __device__ inline size_t aa_table_xmin_off() { return sizeof(aa_table_header); }
+__host__ __device__ inline size_t aa_table_xsize_off(int64_t out) { return sizeof(aa_table_header) + 4 * (size_t)out; }
+__host__ __device__ inline size_t aa_table_w_off(int64_t out) {
+  return aa_align16(sizeof(aa_table_header) + 8 * (size_t)out);
+}
+__host__ __device__ inline size_t aa_table_total_bytes(int kind, int64_t out, int ksize) {
+  return aa_align16(aa_table_w_off(out) + (size_t)out * (size_t)ksize * aa_weight_elem_bytes(kind));
+}
+
+template <typename WT>
+struct TableView {
+  const int32_t *xmin;
+  const int32_t *xsize;
+  const WT *w;
+  int ksize;
+};
+
+template <typename WT>
+__host__ __device__ inline TableView<WT> make_table_view(const void *table, int out_size, int ksize) {
+  const char *p = (const char *)table;
+  TableView<WT> v;
+  v.xmin = (const int32_t *)(p + aa_table_xmin_off());
+  v.xsize = (const int32_t *)(p + aa_table_xsize_off(out_size));
+  v.w = (const WT *)(p + aa_table_w_off(out_size));
+  v.ksize = ksize;
+  return v;
+}
+
+// ---- launch-error plumbing -------------------------------------------------------------------------------
+#define AA_HIP_CHECK_LAUNCH()                 \
+  do {                                        \
+    if (hipGetLastError() != hipSuccess) return AA_ERR_HIP; \
+  } while (0)
+
+// entry points implemented in the .hip files and called from aa_api.cpp
+int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
+                          int ksize, void *table_dev, hipStream_t stream);
+int aa_launch_table_transpose(const aa_table_header &h, const void *table_dev, void *tr_dev, int tr_ksize,
+                              hipStream_t stream);
+
+struct AAProblem {
+  const void *in;
+  void *out;
+  void *ws;
+  size_t ws_bytes;
+  int dtype, layout;
+  int64_t N, C, H, W, oH, oW;
+  aa_axis ah, aw;
+  hipStream_t stream;
+};
+
+// generic two-launch separable path (always available); returns variant name through *variant
+int aa_launch_generic_fwd(const AAProblem &p, const char **variant);
+size_t aa_generic_workspace_bytes(int dtype, int kind_w, int64_t N, int64_t C, int64_t H, int64_t oW);
+// fused single-launch paths; return 1 when they took the problem, 0 when not applicable, <0 on error
+int aa_try_fused_u8_nhwc(const AAProblem &p, const char **variant);
+int aa_try_fused_float_nchw(const AAProblem &p, const char **variant);
+bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
+bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
+// scatter-add adjoint
+int aa_launch_bwd_atomic(const AAProblem &p);

@@ -1,0 +1,159 @@
+// aa_generic.hip — generic separable path: one horizontal-pass launch + one vertical-pass launch with the
+// intermediate in HBM.  Always applicable (any dtype / layout / ksize / scale); the fused single-launch
+// kernels in aa_fused_*.hip take over for the shapes they cover.
+//
+// Replaces the reference's inner kernels and driver:
+//   horizontal body  interpolate_aa_single_dim            s2.2/aa_interpolation_impl.h:60-87  (+ :102-120)
+//   vertical body    interpolate_aa_single_dim_zero_strides                          :29-58   (+ :89-100)
+//   driver           ti_separable_upsample_generic_Nd_kernel_impl (W pass -> temp -> H pass)  :628-683
+// Arithmetic contract (bit-comparable with the reference's CPU build): tap 0 unconditionally, taps 1..xsize-1
+// in order, product and sum rounded separately (this file is built with -ffp-contract=off).
+//
+// Both layouts collapse to the same two kernels:
+//   NCHW: H-pass rows = N*C*H, inner = 1;       V-pass planes = N*C, rowlen = oW
+//   NHWC: H-pass rows = N*H,   inner = C;       V-pass planes = N,   rowlen = oW*C
+// so consecutive threads always touch consecutive output elements (coalesced stores; input rows are read
+// through L1/L2 with ~scale-fold reuse between neighbouring threads).
+
+#include "aa_common.h"
+
+namespace {
+
+// ---- per-pipeline arithmetic -----------------------------------------------------------------------------
+struct PipeF32 {
+  using W = float; using Acc = float;
+  template <typename T> static __device__ inline Acc first(T x, W w) { return (float)x * w; }
+  template <typename T> static __device__ inline Acc next(Acc a, T x, W w) { return a + (float)x * w; }
+};
+struct PipeF64 {
+  using W = double; using Acc = double;
+  template <typename T> static __device__ inline Acc first(T x, W w) { return (double)x * w; }
+  template <typename T> static __device__ inline Acc next(Acc a, T x, W w) { return a + (double)x * w; }
+};
+struct PipePIL {  // Pillow 8bpc: ss0 = 1 << (PRECISION_BITS-1); ss0 += pixel * k[x]
+  using W = int32_t; using Acc = int32_t;
+  template <typename T> static __device__ inline Acc first(T x, W w) { return (1 << 21) + (int32_t)x * w; }
+  template <typename T> static __device__ inline Acc next(Acc a, T x, W w) { return a + (int32_t)x * w; }
+};
+
+template <typename TOut, typename Acc>
+struct Store;
+template <> struct Store<float, float> { static __device__ inline float cvt(float a, int) { return a; } };
+template <> struct Store<double, double> { static __device__ inline double cvt(double a, int) { return a; } };
+template <> struct Store<uint8_t, int32_t> {  // clip8(ss >> PRECISION_BITS)
+  static __device__ inline uint8_t cvt(int32_t a, int) {
+    a >>= 22;
+    return (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
+  }
+};
+template <> struct Store<uint8_t, float> {  // harness: (bicubic clamp, test.py:72) then truncating .byte() (test.py:75)
+  static __device__ inline uint8_t cvt(float a, int) {
+    a = a < 0.f ? 0.f : (a > 255.f ? 255.f : a);
+    return (uint8_t)(int)a;
+  }
+};
+
+// out[row][ox][ci] = sum_j in[row][xmin[ox]+j][ci] * w[ox][j]
+template <typename Pipe, typename TIn, typename TOut>
+__global__ void __launch_bounds__(256)
+hpass_generic(const TIn *__restrict__ in, TOut *__restrict__ out, const char *__restrict__ table, int64_t total,
+              int W, int oW, int inner, int ksize) {
+  using WT = typename Pipe::W;
+  const TableView<WT> tv = make_table_view<WT>(table, oW, ksize);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int ci = (int)(idx % inner);
+    const int64_t t = idx / inner;
+    const int ox = (int)(t % oW);
+    const int64_t row = t / oW;
+    const int xmin = tv.xmin[ox];
+    int n = tv.xsize[ox];
+    n = n > 1 ? n : 1;
+    const WT *w = tv.w + (size_t)ox * ksize;
+    const TIn *src = in + (row * W + xmin) * inner + ci;
+    typename Pipe::Acc acc = Pipe::first(src[0], w[0]);
+    for (int j = 1; j < n; j++) acc = Pipe::next(acc, src[(int64_t)j * inner], w[j]);
+    out[idx] = Store<TOut, typename Pipe::Acc>::cvt(acc, 0);
+  }
+}
+
+// out[p][oy][e] = sum_j mid[p][ymin[oy]+j][e] * w[oy][j]
+template <typename Pipe, typename TIn, typename TOut>
+__global__ void __launch_bounds__(256)
+vpass_generic(const TIn *__restrict__ mid, TOut *__restrict__ out, const char *__restrict__ table, int64_t total,
+              int H, int oH, int64_t rowlen, int ksize) {
+  using WT = typename Pipe::W;
+  const TableView<WT> tv = make_table_view<WT>(table, oH, ksize);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const int64_t e = idx % rowlen;
+    const int64_t t = idx / rowlen;
+    const int oy = (int)(t % oH);
+    const int64_t p = t / oH;
+    const int ymin = tv.xmin[oy];
+    int n = tv.xsize[oy];
+    n = n > 1 ? n : 1;
+    const WT *w = tv.w + (size_t)oy * ksize;
+    const TIn *src = mid + (p * H + ymin) * rowlen + e;
+    typename Pipe::Acc acc = Pipe::first(src[0], w[0]);
+    for (int j = 1; j < n; j++) acc = Pipe::next(acc, src[(int64_t)j * rowlen], w[j]);
+    out[idx] = Store<TOut, typename Pipe::Acc>::cvt(acc, 0);
+  }
+}
+
+inline int grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  const int64_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride beyond
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <typename Pipe, typename TIn, typename TMid, typename TOut>
+int run_two_pass(const AAProblem &p) {
+  const int64_t N = p.N, C = p.C, H = p.H, W = p.W, oH = p.oH, oW = p.oW;
+  const bool nhwc = p.layout == AA_NHWC;
+  const int inner = nhwc ? (int)C : 1;
+  const int64_t hrows = nhwc ? N * H : N * C * H;
+  const int64_t htotal = hrows * oW * inner;
+  TMid *mid = (TMid *)p.ws;
+  hipLaunchKernelGGL((hpass_generic<Pipe, TIn, TMid>), dim3(grid_for(htotal)), dim3(256), 0, p.stream, (const TIn *)p.in,
+                     mid, (const char *)p.aw.table_dev, htotal, (int)W, (int)oW, inner, p.aw.ksize);
+  const int64_t planes = nhwc ? N : N * C;
+  const int64_t rowlen = nhwc ? oW * C : oW;
+  const int64_t vtotal = planes * oH * rowlen;
+  hipLaunchKernelGGL((vpass_generic<Pipe, TMid, TOut>), dim3(grid_for(vtotal)), dim3(256), 0, p.stream, (const TMid *)mid,
+                     (TOut *)p.out, (const char *)p.ah.table_dev, vtotal, (int)H, (int)oH, rowlen, p.ah.ksize);
+  AA_HIP_CHECK_LAUNCH();
+  return AA_OK;
+}
+
+}  // namespace
+
+size_t aa_generic_workspace_bytes(int dtype, int kind_w, int64_t N, int64_t C, int64_t H, int64_t oW) {
+  size_t elem;
+  if (dtype == AA_F64) elem = 8;
+  else if (dtype == AA_F32) elem = 4;
+  else elem = (kind_w == AA_TABLE_PIL) ? 1 : 4;  // u8: Pillow keeps a uint8 intermediate, the harness an fp32 one
+  return aa_align16((size_t)N * C * H * oW * elem);
+}
+
+int aa_launch_generic_fwd(const AAProblem &p, const char **variant) {
+  if (p.dtype == AA_F32 && p.aw.kind == AA_TABLE_F32 && p.ah.kind == AA_TABLE_F32) {
+    *variant = "generic_2pass_f32";
+    return run_two_pass<PipeF32, float, float, float>(p);
+  }
+  if (p.dtype == AA_F64 && p.aw.kind == AA_TABLE_F64 && p.ah.kind == AA_TABLE_F64) {
+    *variant = "generic_2pass_f64";
+    return run_two_pass<PipeF64, double, double, double>(p);
+  }
+  if (p.dtype == AA_U8 && p.aw.kind == AA_TABLE_PIL && p.ah.kind == AA_TABLE_PIL) {
+    *variant = "generic_2pass_u8_pil";
+    return run_two_pass<PipePIL, uint8_t, uint8_t, uint8_t>(p);
+  }
+  if (p.dtype == AA_U8 && p.aw.kind == AA_TABLE_F32 && p.ah.kind == AA_TABLE_F32) {
+    *variant = "generic_2pass_u8_harness";
+    return run_two_pass<PipeF32, uint8_t, float, uint8_t>(p);
+  }
+  return AA_ERR_BAD_DTYPE;
+}

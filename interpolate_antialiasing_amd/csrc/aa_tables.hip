@@ -1,0 +1,255 @@
+// aa_tables.hip — device-side precompute of per-output xmin / xsize / normalised filter weights.
+//
+// Replaces HelperInterpBase::_compute_indices_weights_aa (reference step_two_dot_two/aa_interpolation_impl.h:195-281;
+// older copies step_three/aa_interpolation_impl.h:345-419, step_three/aa_separable_single_dim_loop2d_impl.h:303-377),
+// which runs serially on the calling CPU thread on every call and every pass, and allocates five tensors.  Here it
+// is one launch, one thread per output index, writing ONE packed buffer that is cached by the host and can be
+// broadcast to other GPUs as a single small RCCL message.
+//
+// Built with -ffp-contract=off: a fused multiply-add in `center`, `xmin` or the filter argument moves a window by
+// one pixel (SURVEY §7 "Weight parity").  Float divisions are evaluated in double and narrowed, which is the
+// correctly rounded float quotient (53 >= 2*24+2 bits), so the result does not depend on the fp32 division mode.
+
+#include "aa_common.h"
+
+namespace {
+
+// ---- filters (reference s2.2:292-300, :410-424, :367-372): argument type scalar_t, evaluated in double ----
+template <typename S>
+__device__ inline S filt_linear(S x) {
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return (S)(1.0 - (double)x);
+  return (S)0.0;
+}
+template <typename S>
+__device__ inline S filt_cubic(S x) {
+  const double a = -0.5;
+  if (x < 0.0) x = -x;
+  const double xd = (double)x;
+  if (x < 1.0) return (S)(((a + 2.0) * xd - (a + 3.0)) * xd * xd + 1);
+  if (x < 2.0) return (S)((((xd - 5) * xd + 8) * xd - 4) * a);
+  return (S)0.0;
+}
+template <typename S>
+__device__ inline S filt_box(S x) {
+  return (x > -0.5 && x <= 0.5) ? (S)1.0 : (S)0.0;
+}
+template <typename S>
+__device__ inline S apply_filter(int filter, S x) {
+  return filter == AA_FILTER_LINEAR ? filt_linear<S>(x) : (filter == AA_FILTER_CUBIC ? filt_cubic<S>(x) : filt_box<S>(x));
+}
+
+__device__ inline int interp_size_of(int filter) { return filter == AA_FILTER_LINEAR ? 2 : (filter == AA_FILTER_CUBIC ? 4 : 1); }
+
+// Reference arithmetic, scalar_t = float (s2.2:207-209, :242, :253-278).  Every promotion spelled out.
+__global__ void table_build_f32(int filter, int in_size, int out_size, int ksize, float scale, char *table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= out_size) return;
+  int32_t *xmin_p = (int32_t *)(table + aa_table_xmin_off());
+  int32_t *xsize_p = (int32_t *)(table + aa_table_xsize_off(out_size));
+  float *w = (float *)(table + aa_table_w_off(out_size)) + (size_t)i * ksize;
+  int32_t *max_taps = &((aa_table_header *)table)->max_taps;
+
+  const int interp_size = interp_size_of(filter);
+  const float support = (scale >= 1.0) ? (float)((interp_size * 0.5) * (double)scale) : (float)(interp_size * 0.5);
+  const float invscale = (scale >= 1.0) ? (float)(1.0 / (double)scale) : 1.0f;
+
+  const float center = (float)((double)scale * ((double)i + 0.5));
+  long long xmin = (long long)((double)(float)(center - support) + 0.5);
+  if (xmin < 0) xmin = 0;
+  long long xmax = (long long)((double)(float)(center + support) + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  xmin_p[i] = (int32_t)xmin;
+  xsize_p[i] = (int32_t)xmax;
+
+  float total_w = 0.0f;
+  int j = 0;
+  for (; j < xmax && j < ksize; j++) {
+    const float t = (float)((float)(j + xmin) - center);
+    const float arg = (float)(((double)t + 0.5) * (double)invscale);
+    const float wj = apply_filter<float>(filter, arg);
+    w[j] = wj;
+    total_w = (float)(total_w + wj);
+  }
+  if (total_w != 0.0f) {
+    for (int q = 0; q < j; q++) w[q] = (float)((double)w[q] / (double)total_w);
+  }
+  for (; j < ksize; j++) w[j] = 0.0f;
+  atomicMax(max_taps, (int32_t)(xmax > 1 ? xmax : 1));
+}
+
+// scalar_t = double
+__global__ void table_build_f64(int filter, int in_size, int out_size, int ksize, double scale, char *table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= out_size) return;
+  int32_t *xmin_p = (int32_t *)(table + aa_table_xmin_off());
+  int32_t *xsize_p = (int32_t *)(table + aa_table_xsize_off(out_size));
+  double *w = (double *)(table + aa_table_w_off(out_size)) + (size_t)i * ksize;
+  int32_t *max_taps = &((aa_table_header *)table)->max_taps;
+
+  const int interp_size = interp_size_of(filter);
+  const double support = (scale >= 1.0) ? (interp_size * 0.5) * scale : interp_size * 0.5;
+  const double invscale = (scale >= 1.0) ? 1.0 / scale : 1.0;
+  const double center = scale * ((double)i + 0.5);
+  long long xmin = (long long)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  long long xmax = (long long)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  xmin_p[i] = (int32_t)xmin;
+  xsize_p[i] = (int32_t)xmax;
+  double total_w = 0.0;
+  int j = 0;
+  for (; j < xmax && j < ksize; j++) {
+    const double wj = apply_filter<double>(filter, ((double)(j + xmin) - center + 0.5) * invscale);
+    w[j] = wj;
+    total_w += wj;
+  }
+  if (total_w != 0.0) {
+    for (int q = 0; q < j; q++) w[q] /= total_w;
+  }
+  for (; j < ksize; j++) w[j] = 0.0;
+  atomicMax(max_taps, (int32_t)(xmax > 1 ? xmax : 1));
+}
+
+// Pillow: precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c, cited by URL in the reference:
+// README.md:18,40; s2.2/aa_interpolation_impl.h:289-291).  double coefficients -> 22-bit fixed point int32.
+__global__ void table_build_pil(int filter, int in_size, int out_size, int ksize, char *table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= out_size) return;
+  int32_t *xmin_p = (int32_t *)(table + aa_table_xmin_off());
+  int32_t *xsize_p = (int32_t *)(table + aa_table_xsize_off(out_size));
+  int32_t *kk = (int32_t *)(table + aa_table_w_off(out_size)) + (size_t)i * ksize;
+  int32_t *max_taps = &((aa_table_header *)table)->max_taps;
+
+  double scale = (double)in_size / (double)out_size;
+  double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double fsupport = filter == AA_FILTER_LINEAR ? 1.0 : (filter == AA_FILTER_CUBIC ? 2.0 : 0.5);
+  const double support = fsupport * filterscale;
+  const double center = 0.0 + ((double)i + 0.5) * scale;
+  const double ss = 1.0 / filterscale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  xmin_p[i] = xmin;
+  xsize_p[i] = xmax;
+  // two sweeps (sum, then normalise + quantise) so no per-thread array is needed
+  double ww = 0.0;
+  for (int x = 0; x < xmax && x < ksize; x++) ww += apply_filter<double>(filter, ((double)(x + xmin) - center + 0.5) * ss);
+  int x = 0;
+  for (; x < xmax && x < ksize; x++) {
+    double k = apply_filter<double>(filter, ((double)(x + xmin) - center + 0.5) * ss);
+    if (ww != 0.0) k /= ww;
+    kk[x] = (k < 0) ? (int32_t)(-0.5 + k * (double)(1 << 22)) : (int32_t)(0.5 + k * (double)(1 << 22));
+  }
+  for (; x < ksize; x++) kk[x] = 0;
+  atomicMax(max_taps, (int32_t)(xmax > 1 ? xmax : 1));
+}
+
+__global__ void table_write_header(aa_table_header h, char *table) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *(aa_table_header *)table = h;
+}
+
+// ---- adjoint (gather-form) table -----------------------------------------------------------------------
+// For input index x: outputs whose window [xmin, xmin+max(xsize,1)) holds x form a contiguous range because
+// xmin[] and xmin[]+xsize[] are non-decreasing.  tmin[x] = first such output, tsize[x] = their count,
+// tw[x][k] = w[tmin+k][x - xmin[tmin+k]].
+template <typename WT>
+__global__ void table_transpose_kernel(const char *fwd, char *tr, int in_size, int out_size, int ksize, int tr_ksize) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= in_size) return;
+  const int32_t *xmin = (const int32_t *)(fwd + aa_table_xmin_off());
+  const int32_t *xsize = (const int32_t *)(fwd + aa_table_xsize_off(out_size));
+  const WT *w = (const WT *)(fwd + aa_table_w_off(out_size));
+  int32_t *tmin = (int32_t *)(tr + aa_table_xmin_off());
+  int32_t *tsize = (int32_t *)(tr + aa_table_xsize_off(in_size));
+  WT *tw = (WT *)(tr + aa_table_w_off(in_size)) + (size_t)x * tr_ksize;
+  int32_t *max_taps = &((aa_table_header *)tr)->max_taps;
+
+  // lo = first o with xmin[o] + max(xsize[o],1) > x
+  int lo = 0, hi = out_size;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int xs = xsize[mid] > 1 ? xsize[mid] : 1;
+    if (xmin[mid] + xs > x) hi = mid; else lo = mid + 1;
+  }
+  const int first = lo;
+  // end = first o with xmin[o] > x
+  lo = first; hi = out_size;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (xmin[mid] > x) hi = mid; else lo = mid + 1;
+  }
+  int cnt = lo - first;
+  if (cnt < 0) cnt = 0;
+  if (cnt > tr_ksize) cnt = tr_ksize;  // cannot happen when tr_ksize comes from aa_table_transposed_ksize
+  tmin[x] = cnt > 0 ? first : 0;
+  tsize[x] = cnt;
+  int k = 0;
+  for (; k < cnt; k++) {
+    const int o = first + k;
+    tw[k] = w[(size_t)o * ksize + (x - xmin[o])];
+  }
+  for (; k < tr_ksize; k++) tw[k] = (WT)0;
+  atomicMax(max_taps, cnt > 1 ? cnt : 1);
+}
+
+}  // namespace
+
+int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
+                          int ksize, void *table_dev, hipStream_t stream) {
+  aa_table_header h = {};
+  h.magic = AA_TABLE_MAGIC;
+  h.filter = filter;
+  h.kind = kind;
+  h.in_size = (int32_t)in_size;
+  h.out_size = (int32_t)out_size;
+  h.ksize = ksize;
+  h.align_corners = align_corners;
+  h.max_taps = 0;
+  h.transposed = 0;
+  char *t = (char *)table_dev;
+  hipLaunchKernelGGL(table_write_header, dim3(1), dim3(64), 0, stream, h, t);
+  const int threads = 128;
+  const int blocks = (int)((out_size + threads - 1) / threads);
+  if (kind == AA_TABLE_F32) {
+    hipLaunchKernelGGL(table_build_f32, dim3(blocks), dim3(threads), 0, stream, filter, (int)in_size, (int)out_size, ksize,
+                       (float)scale, t);
+  } else if (kind == AA_TABLE_F64) {
+    hipLaunchKernelGGL(table_build_f64, dim3(blocks), dim3(threads), 0, stream, filter, (int)in_size, (int)out_size, ksize,
+                       scale, t);
+  } else {
+    hipLaunchKernelGGL(table_build_pil, dim3(blocks), dim3(threads), 0, stream, filter, (int)in_size, (int)out_size, ksize,
+                       t);
+  }
+  AA_HIP_CHECK_LAUNCH();
+  return AA_OK;
+}
+
+int aa_launch_table_transpose(const aa_table_header &fh, const void *table_dev, void *tr_dev, int tr_ksize,
+                              hipStream_t stream) {
+  aa_table_header h = fh;
+  h.in_size = fh.out_size;
+  h.out_size = fh.in_size;
+  h.ksize = tr_ksize;
+  h.max_taps = 0;
+  h.transposed = 1;
+  char *t = (char *)tr_dev;
+  hipLaunchKernelGGL(table_write_header, dim3(1), dim3(64), 0, stream, h, t);
+  const int threads = 128;
+  const int blocks = (fh.in_size + threads - 1) / threads;
+  if (fh.kind == AA_TABLE_F32) {
+    hipLaunchKernelGGL(table_transpose_kernel<float>, dim3(blocks), dim3(threads), 0, stream, (const char *)table_dev, t,
+                       fh.in_size, fh.out_size, fh.ksize, tr_ksize);
+  } else if (fh.kind == AA_TABLE_F64) {
+    hipLaunchKernelGGL(table_transpose_kernel<double>, dim3(blocks), dim3(threads), 0, stream, (const char *)table_dev, t,
+                       fh.in_size, fh.out_size, fh.ksize, tr_ksize);
+  } else {
+    return AA_ERR_BAD_DTYPE;
+  }
+  AA_HIP_CHECK_LAUNCH();
+  return AA_OK;
+}

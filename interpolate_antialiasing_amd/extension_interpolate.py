@@ -1,0 +1,278 @@
+"""Drop-in operator surface of the reference's pybind11 module, running on MI355X.
+
+Mirrors step_two_dot_two/extension_interpolate.cpp:46-51 (same names, argument meaning, error behaviour):
+
+    linear_forward(input, output_size, align_corners=False)   -> Tensor      (:7-14)
+    nearest_forward(input, output_size, align_corners=False)  -> Tensor      (:26-33; "it's not nearest but box")
+    cubic_forward(input, output_size, align_corners=False)    -> Tensor      (:35-42)
+    linear_backward(grad_output, output_size, input_size, align_corners=False) -> Tensor   (:16-24)
+    forward(...)                                               legacy name of linear_forward used by every other
+                                                               step (step_three/extension_interpolate.cpp:17-19)
+plus cubic_backward / nearest_backward (the commented-out intent at test.py:111-116).
+
+``output_size`` is (H, W); ``input_size`` is the full NCHW size (test.py:140-143).  antialias=True and
+scale_factors={} are hard-wired exactly as in the reference wrappers.  The callee allocates and returns a fresh
+tensor whose memory format follows the input (aa_interpolation_impl.h:739,752).
+
+Differences, all additive:
+  * tensors must live on a ROCm GPU — this package is the HIP path only and has no CPU implementation;
+  * uint8 input is accepted for linear/cubic/box (the reference dispatches floating types only, :609-614): the
+    default ``uint8_mode="pil"`` is bit-exact with PIL.Image.resize (integer arithmetic, uint8 intermediate);
+    ``uint8_mode="harness"`` reproduces test.py:52-58,72,75 (float(), fp32 op, clamp for bicubic, truncating byte());
+  * the backward is the TRUE adjoint of the antialiased forward (the reference header's is the non-AA one);
+  * the same callables are registered as ``torch.ops.extension_interpolate.*``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib, tables
+
+__all__ = ["linear_forward", "nearest_forward", "cubic_forward", "linear_backward", "cubic_backward",
+           "nearest_backward", "forward", "set_uint8_mode", "get_uint8_mode", "last_variant"]
+
+_uint8_mode = "pil"
+
+_DTYPE_IDS = {torch.uint8: _lib.U8, torch.float32: _lib.F32, torch.float64: _lib.F64}
+_DTYPE_NAMES = {torch.float16: "Half", torch.bfloat16: "BFloat16", torch.int8: "Char", torch.int16: "Short",
+                torch.int32: "Int", torch.int64: "Long", torch.bool: "Bool", torch.uint8: "Byte"}
+
+
+def set_uint8_mode(mode: str) -> None:
+    global _uint8_mode
+    if mode not in ("pil", "harness"):
+        raise ValueError("uint8_mode must be 'pil' or 'harness'")
+    _uint8_mode = mode
+
+
+def get_uint8_mode() -> str:
+    return _uint8_mode
+
+
+def last_variant() -> str:
+    """Kernel variant the last forward on this thread dispatched to."""
+    return _lib.last_variant()
+
+
+# ---- argument checks with the reference's wording (ATen upsample_2d_common_check; s2.2:744-750) -------------
+def _check_sizes(input_size: Sequence[int], output_size: Sequence[int]):
+    if len(output_size) != 2:
+        raise RuntimeError(f"It is expected output_size equals to 2, but got size {len(output_size)}")
+    if len(input_size) != 4:
+        raise RuntimeError(f"It is expected input_size equals to 4, but got size {len(input_size)}")
+    n, c, h, w = (int(v) for v in input_size)
+    oh, ow = int(output_size[0]), int(output_size[1])
+    if not (h > 0 and w > 0 and oh > 0 and ow > 0):
+        raise RuntimeError("Input and output sizes should be greater than 0, but got "
+                           f"input (H: {h}, W: {w}) output (H: {oh}, W: {ow})")
+    return n, c, h, w, oh, ow
+
+
+def _memory_format(x: torch.Tensor):
+    """input.suggest_memory_format() restricted to the two dense layouts the kernels take; anything else is
+    made contiguous first (the reference walks arbitrary strides through TensorIterator)."""
+    if x.is_contiguous():
+        return x, _lib.NCHW
+    if x.is_contiguous(memory_format=torch.channels_last):
+        return x, _lib.NHWC
+    return x.contiguous(), _lib.NCHW
+
+
+def _table_kind(dtype: torch.dtype, uint8_mode: Optional[str]) -> int:
+    if dtype == torch.float32:
+        return _lib.TABLE_F32
+    if dtype == torch.float64:
+        return _lib.TABLE_F64
+    mode = uint8_mode or _uint8_mode
+    if mode not in ("pil", "harness"):
+        raise ValueError("uint8_mode must be 'pil' or 'harness'")
+    return _lib.TABLE_PIL if mode == "pil" else _lib.TABLE_F32
+
+
+def _require_gpu(x: torch.Tensor, what: str):
+    if not x.is_cuda:
+        raise _lib.AAInterpError(
+            f"{what}: expected a tensor on a ROCm GPU, got device '{x.device}'. interpolate_antialiasing_amd is the "
+            "MI355X HIP path only and has no CPU implementation.")
+
+
+def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequence[int], align_corners: bool,
+             uint8_mode: Optional[str] = None) -> torch.Tensor:
+    if not isinstance(input, torch.Tensor):
+        raise TypeError(f"{name}(): argument 'input' must be Tensor")
+    n, c, h, w, oh, ow = _check_sizes(input.shape, output_size)
+    if input.numel() == 0 and (c == 0):  # empty batch allowed, nothing else (s2.2:747-750)
+        raise RuntimeError(f"Non-empty 4D data tensor expected but got a tensor with sizes {list(input.shape)}")
+    if input.dtype not in _DTYPE_IDS:
+        raise NotImplementedError(f'"upsample_generic_Nd" not implemented for \'{_DTYPE_NAMES.get(input.dtype, str(input.dtype))}\'')
+    _require_gpu(input, name)
+    L = _lib.load()
+    x, layout = _memory_format(input)
+    kind = _table_kind(x.dtype, uint8_mode)
+    if kind == _lib.TABLE_PIL and align_corners:
+        raise NotImplementedError("uint8_mode='pil' has no align_corners (Pillow has none); use uint8_mode='harness'")
+    dev = x.device
+    mf = torch.channels_last if layout == _lib.NHWC else torch.contiguous_format
+    out = torch.empty((n, c, oh, ow), dtype=x.dtype, device=dev, memory_format=mf)
+    if n == 0:
+        return out
+    with torch.cuda.device(dev):
+        th = tables.get_table(filter_id, kind, h, oh, align_corners, 0.0, dev)
+        tw = tables.get_table(filter_id, kind, w, ow, align_corners, 0.0, dev)
+        ah, aw = th.axis(), tw.axis()
+        dt = _DTYPE_IDS[x.dtype]
+        ws_bytes = L.aa_workspace_bytes(dt, layout, n, c, h, w, oh, ow, ctypes.byref(ah), ctypes.byref(aw))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        rc = L.aa_resample_fwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                               ctypes.c_void_p(ws.data_ptr() if ws is not None else 0), ws_bytes, dt, layout,
+                               n, c, h, w, ctypes.byref(ah), ctypes.byref(aw), tables._stream_ptr(dev))
+    _lib.check(rc, name)
+    return out
+
+
+def _backward(filter_id: int, name: str, grad_output: torch.Tensor, output_size: Sequence[int],
+              input_size: Sequence[int], align_corners: bool, atomic: bool = False) -> torch.Tensor:
+    n, c, h, w, oh, ow = _check_sizes(input_size, output_size)
+    # ti_upsample_bilinear2d_backward_cpu checks (s2.2/aa_interpolation_backward_impl.h:202-212)
+    if grad_output.dim() != 4:
+        raise RuntimeError(f"Expected grad_output to be a tensor of dimension 4 but got: dimension {grad_output.dim()}")
+    full = (n, c, oh, ow)
+    for i in range(4):
+        if grad_output.size(i) != full[i]:
+            raise RuntimeError("Expected grad_output to have the same shape as output; "
+                               f"output.size({i}) = {full[i]} but got grad_output.size({i}) = {grad_output.size(i)}")
+    if grad_output.dtype not in (torch.float32, torch.float64):
+        raise NotImplementedError(f'"ti_upsample_bilinear2d_backward_cpu" not implemented for '
+                                  f'\'{_DTYPE_NAMES.get(grad_output.dtype, str(grad_output.dtype))}\'')
+    _require_gpu(grad_output, name)
+    L = _lib.load()
+    go, layout = _memory_format(grad_output)
+    dev = go.device
+    mf = torch.channels_last if layout == _lib.NHWC else torch.contiguous_format
+    gi = torch.empty((n, c, h, w), dtype=go.dtype, device=dev, memory_format=mf)
+    if n == 0:
+        return gi
+    kind = _lib.TABLE_F32 if go.dtype == torch.float32 else _lib.TABLE_F64
+    dt = _DTYPE_IDS[go.dtype]
+    with torch.cuda.device(dev):
+        th = tables.get_table(filter_id, kind, h, oh, align_corners, 0.0, dev)
+        tw = tables.get_table(filter_id, kind, w, ow, align_corners, 0.0, dev)
+        s = tables._stream_ptr(dev)
+        if atomic:
+            ah, aw = th.axis(), tw.axis()
+            ws_bytes = L.aa_workspace_bytes_bwd(dt, layout, n, c, h, w, oh, ow)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            rc = L.aa_resample_bwd_atomic(ctypes.c_void_p(go.data_ptr()), ctypes.c_void_p(gi.data_ptr()),
+                                          ctypes.c_void_p(ws.data_ptr()), ws_bytes, dt, layout, n, c, h, w,
+                                          ctypes.byref(ah), ctypes.byref(aw), s)
+        else:
+            trh = tables.get_transposed_table(th).axis()
+            trw = tables.get_transposed_table(tw).axis()
+            # the gather-form adjoint is a forward resample of grad_out with the transposed tables
+            ws_bytes = L.aa_workspace_bytes(dt, layout, n, c, oh, ow, h, w, ctypes.byref(trh), ctypes.byref(trw))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+            rc = L.aa_resample_bwd(ctypes.c_void_p(go.data_ptr()), ctypes.c_void_p(gi.data_ptr()),
+                                   ctypes.c_void_p(ws.data_ptr() if ws is not None else 0), ws_bytes, dt, layout,
+                                   n, c, h, w, ctypes.byref(trh), ctypes.byref(trw), s)
+    _lib.check(rc, name)
+    return gi
+
+
+# ---- the reference's callables ---------------------------------------------------------------------------
+def linear_forward(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False, *,
+                   uint8_mode: Optional[str] = None) -> torch.Tensor:
+    """Anti-Aliased Linear Interpolation forward (s2.2/extension_interpolate.cpp:7-14,47)."""
+    return _forward(_lib.FILTER_LINEAR, "linear_forward", input, output_size, align_corners, uint8_mode)
+
+
+def nearest_forward(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False, *,
+                    uint8_mode: Optional[str] = None) -> torch.Tensor:
+    """Anti-Aliased "Nearest" (really: box filter) forward (s2.2/extension_interpolate.cpp:26-33,48)."""
+    return _forward(_lib.FILTER_BOX, "nearest_forward", input, output_size, align_corners, uint8_mode)
+
+
+def cubic_forward(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False, *,
+                  uint8_mode: Optional[str] = None) -> torch.Tensor:
+    """Anti-Aliased Cubic Interpolation forward (s2.2/extension_interpolate.cpp:35-42,49)."""
+    return _forward(_lib.FILTER_CUBIC, "cubic_forward", input, output_size, align_corners, uint8_mode)
+
+
+def linear_backward(grad_output: torch.Tensor, output_size: Sequence[int], input_size: Sequence[int],
+                    align_corners: bool = False, *, atomic: bool = False) -> torch.Tensor:
+    """Backward of linear_forward (s2.2/extension_interpolate.cpp:16-24,50) — the true AA adjoint."""
+    return _backward(_lib.FILTER_LINEAR, "linear_backward", grad_output, output_size, input_size, align_corners, atomic)
+
+
+def cubic_backward(grad_output: torch.Tensor, output_size: Sequence[int], input_size: Sequence[int],
+                   align_corners: bool = False, *, atomic: bool = False) -> torch.Tensor:
+    """Backward of cubic_forward (intent at test.py:111-116)."""
+    return _backward(_lib.FILTER_CUBIC, "cubic_backward", grad_output, output_size, input_size, align_corners, atomic)
+
+
+def nearest_backward(grad_output: torch.Tensor, output_size: Sequence[int], input_size: Sequence[int],
+                     align_corners: bool = False, *, atomic: bool = False) -> torch.Tensor:
+    return _backward(_lib.FILTER_BOX, "nearest_backward", grad_output, output_size, input_size, align_corners, atomic)
+
+
+# legacy export of every step but step_two_dot_two (step_three/extension_interpolate.cpp:17-19)
+forward = linear_forward
+
+
+# ---- torch.ops.extension_interpolate.* ---------------------------------------------------------------------
+def _register_torch_ops() -> None:
+    lib = torch.library.Library("extension_interpolate", "DEF")
+    fwd_schema = "(Tensor input, int[] output_size, bool align_corners=False) -> Tensor"
+    bwd_schema = "(Tensor grad_output, int[] output_size, int[] input_size, bool align_corners=False) -> Tensor"
+    fwds = {"linear_forward": linear_forward, "nearest_forward": nearest_forward, "cubic_forward": cubic_forward,
+            "forward": linear_forward}
+    bwds = {"linear_backward": linear_backward, "cubic_backward": cubic_backward, "nearest_backward": nearest_backward}
+    for name in fwds:
+        lib.define(name + fwd_schema)
+    for name in bwds:
+        lib.define(name + bwd_schema)
+
+    def _mf(x):
+        return torch.channels_last if (x.dim() == 4 and not x.is_contiguous()
+                                       and x.is_contiguous(memory_format=torch.channels_last)) else torch.contiguous_format
+
+    for name, fn in fwds.items():
+        lib.impl(name, (lambda f: lambda input, output_size, align_corners=False: f(input, output_size, align_corners))(fn), "CUDA")
+        lib.impl(name, lambda input, output_size, align_corners=False: torch.empty(
+            (input.shape[0], input.shape[1], output_size[0], output_size[1]), dtype=input.dtype, device=input.device,
+            memory_format=_mf(input)), "Meta")
+    for name, fn in bwds.items():
+        lib.impl(name, (lambda f: lambda grad_output, output_size, input_size, align_corners=False:
+                        f(grad_output, output_size, input_size, align_corners))(fn), "CUDA")
+        lib.impl(name, lambda grad_output, output_size, input_size, align_corners=False: torch.empty(
+            tuple(input_size), dtype=grad_output.dtype, device=grad_output.device, memory_format=_mf(grad_output)), "Meta")
+
+    # autograd: d(forward)/d(input) is the matching backward op (true adjoint)
+    def _make_autograd(fwd_name, bwd_name):
+        def setup_context(ctx, inputs, output):
+            input, output_size, align_corners = inputs
+            ctx.in_shape = tuple(input.shape)
+            ctx.out_size = tuple(output_size)
+            ctx.align_corners = align_corners
+
+        def backward(ctx, grad):
+            op = getattr(torch.ops.extension_interpolate, bwd_name)
+            return op(grad, list(ctx.out_size), list(ctx.in_shape), ctx.align_corners), None, None
+
+        torch.library.register_autograd(f"extension_interpolate::{fwd_name}", backward, setup_context=setup_context, lib=lib)
+
+    _make_autograd("linear_forward", "linear_backward")
+    _make_autograd("forward", "linear_backward")
+    _make_autograd("cubic_forward", "cubic_backward")
+    _make_autograd("nearest_forward", "nearest_backward")
+    globals()["_torch_library"] = lib  # keep alive
+
+
+try:
+    _register_torch_ops()
+except Exception as _e:  # pragma: no cover - registration problems must not hide the direct callables
+    import warnings
+
+    warnings.warn(f"torch.ops.extension_interpolate registration failed: {_e}")

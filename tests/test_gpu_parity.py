@@ -1,0 +1,307 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the Python shim -> C-ABI, against the oracle,
+the committed golden vectors and size-independent properties at BASELINE.json's full sizes.
+
+Bars: bit-exact for uint8 (Pillow semantics and harness semantics) and for the weight tables; fp32/fp64
+forward is ALSO held bit-exact against the reference build's outputs (the kernels round product and sum
+separately, in tap order, like the reference's CPU code) — the north-star tolerance is 1e-4 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+FILTS = ("linear", "cubic", "box")
+
+
+@pytest.fixture(scope="module")
+def aa():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from interpolate_antialiasing_amd import extension_interpolate
+
+    return extension_interpolate
+
+
+def _fn(aa, filt):
+    return {"linear": aa.linear_forward, "cubic": aa.cubic_forward, "box": aa.nearest_forward}[filt]
+
+
+def _gpu(a, channels_last=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    if channels_last:
+        t = t.contiguous(memory_format=torch.channels_last)
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ tables
+def test_device_tables_bit_exact(aa, golden_tables):
+    from interpolate_antialiasing_amd import _lib, tables
+
+    n = 0
+    for key in sorted({k.rsplit("_", 1)[0] for k in golden_tables.files}):
+        filt, n_in, n_out, dt = key.split("_")
+        kind = _lib.TABLE_F32 if dt == "float32" else _lib.TABLE_F64
+        t = tables.build_table(oracle.FILTERS[filt], kind, int(n_in), int(n_out), False, 0.0, torch.device("cuda"))
+        xmin, xsize, w = t.unpack()
+        assert t.ksize == int(golden_tables[key + "_ksize"]), key
+        assert np.array_equal(xmin, golden_tables[key + "_xmin"]), key
+        assert np.array_equal(xsize, golden_tables[key + "_xsize"]), key
+        assert np.array_equal(w, golden_tables[key + "_w"]), key
+        assert t.max_taps == max(1, int(xsize.max())), key
+        n += 1
+    assert n >= 40
+
+
+@pytest.mark.parametrize("filt", FILTS)
+def test_device_pil_tables_bit_exact(aa, filt):
+    from interpolate_antialiasing_amd import _lib, tables
+
+    for n_in, n_out in [(906, 320), (438, 196), (1024, 224), (906, 1200), (438, 1200), (53, 23), (61, 1), (3, 2), (64, 64)]:
+        k, xmin, xsize, kk, _ = oracle.pil_coeffs(filt, n_in, n_out)
+        t = tables.build_table(oracle.FILTERS[filt], _lib.TABLE_PIL, n_in, n_out, False, 0.0, torch.device("cuda"))
+        dxmin, dxsize, dw = t.unpack()
+        assert t.ksize == k
+        assert np.array_equal(dxmin, xmin) and np.array_equal(dxsize, xsize) and np.array_equal(dw, kk), (filt, n_in, n_out)
+
+
+def test_align_corners_tables(aa):
+    from interpolate_antialiasing_amd import _lib, tables
+
+    for filt in ("linear", "cubic"):
+        for dt, kind in ((np.float32, _lib.TABLE_F32), (np.float64, _lib.TABLE_F64)):
+            k, xmin, xsize, w = oracle.weights(filt, 31, 11, True, dt)
+            t = tables.build_table(oracle.FILTERS[filt], kind, 31, 11, True, 0.0, torch.device("cuda"))
+            dxmin, dxsize, dw = t.unpack()
+            assert t.ksize == k and np.array_equal(dxmin, xmin) and np.array_equal(dxsize, xsize) and np.array_equal(dw, w)
+
+
+# ------------------------------------------------------------------------------------------------ forward, float
+@pytest.mark.parametrize("case", list("abcdefg"))
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_forward_vs_reference_golden(aa, golden_forward, case, channels_last):
+    x = golden_forward[f"{case}_x"]
+    size = [int(v) for v in golden_forward[f"{case}_size"]]
+    ac = bool(golden_forward[f"{case}_align"])
+    for filt in FILTS:
+        for dt in ("f32", "f64"):
+            xin = x if dt == "f32" else x.astype(np.float64)
+            y = _fn(aa, filt)(_gpu(xin, channels_last), size, ac)
+            exp = golden_forward[f"{case}_{filt}_{dt}"]
+            assert y.shape == exp.shape
+            if channels_last and x.shape[1] > 1:
+                assert y.is_contiguous(memory_format=torch.channels_last)  # s2.2:752
+            got = y.cpu().numpy()
+            # north-star tolerance ...
+            np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-4)
+            # ... and the stronger bar this build holds: identical bits
+            assert np.array_equal(got, exp), (case, filt, dt, float(np.abs(got - exp).max()))
+
+
+def test_forward_known_answer_and_headline_fp32(aa, golden_kat):
+    rgb = golden_kat["rgb"]
+    x = np.ascontiguousarray(rgb.transpose(2, 0, 1)[None]).astype(np.float32)  # config 0: fp32 NCHW [1,3,438,906]
+    y = aa.linear_forward(_gpu(x), [196, 320], False).cpu().numpy()
+    assert np.array_equal(y, golden_kat["lin_320x196_f32"])
+    yc = aa.cubic_forward(_gpu(x), [196, 320], False).cpu().numpy()
+    assert np.array_equal(yc, golden_kat["cubic_320x196_f32"])
+    # the reference's committed PNG = truncation of the fp32 result (test.py:75)
+    assert np.array_equal(y[0].astype(np.uint8).transpose(1, 2, 0), golden_kat["lin_320x196_u8"])
+
+
+@pytest.mark.parametrize("shape,size", [((3, 3, 97, 131), (41, 37)), ((2, 1, 64, 300), (100, 64)), ((1, 5, 9, 1000), (9, 77)),
+                                        ((4, 3, 438, 906), (196, 320)), ((1, 3, 1024, 1024), (224, 224))])
+def test_forward_random_vs_oracle(aa, shape, size):
+    rng = np.random.default_rng(hash((shape, size)) % (2**32))
+    x = (rng.random(shape, dtype=np.float32) * 255).astype(np.float32)
+    for filt in FILTS:
+        for cl in (False, True):
+            exp = oracle.forward(filt, x, size, nthreads=8)
+            got = _fn(aa, filt)(_gpu(x, cl), list(size), False).cpu().numpy()
+            assert np.array_equal(got, exp), (filt, cl, float(np.abs(got - exp).max()))
+
+
+# ------------------------------------------------------------------------------------------------ forward, uint8
+def test_u8_pil_golden(aa, golden_pil, golden_kat):
+    n = 0
+    for key in golden_pil.files:
+        parts = key.split("_")
+        if len(parts) != 3 or "x" not in parts[1]:
+            continue
+        src = golden_pil[parts[0]]
+        ow, oh = map(int, parts[1].split("x"))
+        a = src if src.ndim == 3 else src[..., None]
+        # NHWC storage viewed as NCHW = torch channels_last (config 1's layout)
+        x = torch.from_numpy(a.copy()).cuda().permute(2, 0, 1)[None]
+        y = _fn(aa, parts[2])(x, [oh, ow], False, uint8_mode="pil")
+        got = y[0].permute(1, 2, 0).cpu().numpy()
+        got = got if src.ndim == 3 else got[..., 0]
+        assert np.array_equal(got, golden_pil[key]), key
+        # plain NCHW-contiguous input gives the same values
+        y2 = _fn(aa, parts[2])(x.contiguous(), [oh, ow], False, uint8_mode="pil")
+        assert torch.equal(y2, y.contiguous()), key
+        n += 1
+    assert n >= 50
+
+
+def test_u8_headline_config_pil_parity(aa, golden_kat):
+    """BASELINE config 1: uint8 channels_last [1,3,438,906] -> [196,320] bilinear, PIL parity (MaxAbsE <= 1.0)."""
+    rgb = golden_kat["rgb"]
+    x = torch.from_numpy(rgb.copy()).cuda().permute(2, 0, 1)[None]
+    assert x.is_contiguous(memory_format=torch.channels_last)
+    y = aa.linear_forward(x, [196, 320], False)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    got = y[0].permute(1, 2, 0).cpu().numpy()
+    d = np.abs(got.astype(int) - golden_kat["pil_lin_320x196"].astype(int))
+    assert d.max() <= 1.0
+    assert d.max() == 0  # Pillow semantics: exact
+    yb = aa.cubic_forward(x, [196, 320], False)[0].permute(1, 2, 0).cpu().numpy()
+    assert np.array_equal(yb, golden_kat["pil_cubic_320x196"])
+    # harness semantics reproduce the reference's committed PNG bit for bit, and test.py:370-372's thresholds
+    yh = aa.linear_forward(x, [196, 320], False, uint8_mode="harness")[0].permute(1, 2, 0).cpu().numpy()
+    assert np.array_equal(yh, golden_kat["lin_320x196_u8"])
+    d = np.abs(yh.astype(int) - golden_kat["pil_lin_320x196"].astype(int))
+    assert d.mean() < 1.0 and d.max() < 1.0 + 1e-5
+
+
+@pytest.mark.parametrize("shape,size", [((5, 3, 438, 906), (196, 320)), ((3, 3, 906, 438), (320, 196)), ((2, 4, 50, 70), (31, 22)),
+                                        ((2, 1, 33, 47), (66, 20)), ((1, 3, 1024, 1024), (224, 224)), ((2, 3, 100, 37), (100, 90)),
+                                        ((7, 3, 64, 64), (1, 1)), ((1, 2, 5, 4), (40, 33))])
+def test_u8_random_vs_oracle(aa, shape, size):
+    rng = np.random.default_rng(hash((shape, size)) % (2**32))
+    x = rng.integers(0, 256, shape, dtype=np.uint8)
+    for filt in FILTS:
+        for cl in (False, True):
+            xin = oracle.as_channels_last(x) if cl else x
+            exp = oracle.pil_resize_u8(filt, xin, size, nthreads=8)
+            got = _fn(aa, filt)(_gpu(x, cl), list(size), False, uint8_mode="pil").cpu().numpy()
+            assert np.array_equal(got, exp), (filt, cl)
+            exph = oracle.harness_u8(filt, xin, size, nthreads=8)
+            goth = _fn(aa, filt)(_gpu(x, cl), list(size), False, uint8_mode="harness").cpu().numpy()
+            assert np.array_equal(goth, exph), (filt, cl, "harness")
+
+
+def test_u8_extremes(aa):
+    """Saturation paths: all-0, all-255 and checkerboards through the bicubic (negative lobes -> clip8)."""
+    for val in (0, 255):
+        x = torch.full((2, 3, 64, 80), val, dtype=torch.uint8, device="cuda").contiguous(memory_format=torch.channels_last)
+        for f in (aa.linear_forward, aa.cubic_forward, aa.nearest_forward):
+            assert int(f(x, [23, 31]).float().sub(val).abs().max()) == 0
+    yy, xx = np.meshgrid(np.arange(64), np.arange(80), indexing="ij")
+    cb = (((yy // 3 + xx // 3) % 2) * 255).astype(np.uint8)[None, None].repeat(3, 1)
+    exp = oracle.pil_resize_u8("cubic", cb, (23, 31))
+    got = aa.cubic_forward(_gpu(cb), [23, 31]).cpu().numpy()
+    assert np.array_equal(got, exp)
+
+
+# ------------------------------------------------------------------------------------------------ full-size properties
+def test_fullsize_properties(aa):
+    """BASELINE sizes, no oracle needed: batch independence, constants preserved (weights sum to 1), linearity."""
+    torch.manual_seed(0)
+    x = torch.randint(0, 256, (64, 3, 438, 906), dtype=torch.uint8, device="cuda").contiguous(memory_format=torch.channels_last)
+    y = aa.linear_forward(x, [196, 320])
+    for i in (0, 17, 63):
+        assert torch.equal(aa.linear_forward(x[i:i + 1], [196, 320]), y[i:i + 1])
+    # a checksum of checksums that must not depend on batch order
+    perm = torch.randperm(64, device="cuda")
+    yp = aa.linear_forward(x[perm].contiguous(memory_format=torch.channels_last), [196, 320])
+    assert torch.equal(yp, y[perm])
+    c = torch.full((8, 3, 906, 438), 37, dtype=torch.uint8, device="cuda")
+    assert torch.equal(aa.linear_forward(c, [320, 196]), torch.full((8, 3, 320, 196), 37, dtype=torch.uint8, device="cuda"))
+    # fp32: linearity F(a x + b z) = a F(x) + b F(z) within rounding, bicubic [*,3,1024,1024] -> [224,224] (config 2)
+    a = torch.rand(4, 3, 1024, 1024, device="cuda")
+    b = torch.rand(4, 3, 1024, 1024, device="cuda")
+    lhs = aa.cubic_forward(2.0 * a - 3.0 * b, [224, 224])
+    rhs = 2.0 * aa.cubic_forward(a, [224, 224]) - 3.0 * aa.cubic_forward(b, [224, 224])
+    assert float((lhs - rhs).abs().max()) < 1e-4
+    ones = torch.ones(2, 3, 1024, 1024, device="cuda")
+    assert float((aa.cubic_forward(ones, [224, 224]) - 1).abs().max()) < 1e-5
+
+
+def test_empty_batch_and_errors(aa):
+    x = torch.zeros(0, 3, 8, 8, device="cuda")
+    assert tuple(aa.linear_forward(x, [4, 4]).shape) == (0, 3, 4, 4)  # s2.2:747-750
+    with pytest.raises(RuntimeError, match="Input and output sizes should be greater than 0"):
+        aa.linear_forward(torch.zeros(1, 3, 8, 8, device="cuda"), [0, 4])
+    with pytest.raises(RuntimeError, match="It is expected input_size equals to 4"):
+        aa.linear_forward(torch.zeros(3, 8, 8, device="cuda"), [4, 4])
+    with pytest.raises(RuntimeError, match="It is expected output_size equals to 2"):
+        aa.linear_forward(torch.zeros(1, 3, 8, 8, device="cuda"), [4])
+    with pytest.raises(NotImplementedError, match="not implemented for 'Half'"):
+        aa.linear_forward(torch.zeros(1, 3, 8, 8, device="cuda", dtype=torch.float16), [4, 4])
+
+
+def test_noncontiguous_input(aa):
+    x = torch.rand(2, 3, 40, 60, device="cuda")[:, :, ::2, 5:50]
+    exp = oracle.forward("linear", x.cpu().numpy().copy(), (7, 11))
+    assert np.array_equal(aa.linear_forward(x, [7, 11]).cpu().numpy(), exp)
+
+
+# ------------------------------------------------------------------------------------------------ backward
+@pytest.mark.parametrize("case", list("abc"))
+@pytest.mark.parametrize("atomic", [False, True])
+def test_backward_true_adjoint_golden(aa, golden_backward, case, atomic):
+    go = golden_backward[f"{case}_go"]
+    h, w = (int(v) for v in golden_backward[f"{case}_in_hw"])
+    n, c, oh, ow = go.shape
+    for filt, bw in (("linear", aa.linear_backward), ("cubic", aa.cubic_backward)):
+        exp = golden_backward[f"{case}_{filt}_gi"]  # fp64 autograd of F.interpolate(antialias=True)
+        g64 = bw(_gpu(go), [oh, ow], [n, c, h, w], False, atomic=atomic).cpu().numpy()
+        assert np.abs(g64 - exp).max() < 1e-11
+        g32 = bw(_gpu(go.astype(np.float32)), [oh, ow], [n, c, h, w], False, atomic=atomic).cpu().numpy()
+        np.testing.assert_allclose(g32, exp, rtol=1e-4, atol=1e-4)
+        gcl = bw(_gpu(go, True), [oh, ow], [n, c, h, w], False, atomic=atomic)
+        assert np.abs(gcl.cpu().numpy() - exp).max() < 1e-11
+    # and NOT the header's non-AA backward
+    assert np.abs(g32 - golden_backward[f"{case}_legacy_nonaa_gi"]).max() > 0.1 or case == "never"
+
+
+def test_backward_fullsize_adjoint_identity(aa):
+    """Config 5: grad [1,3,196,320] -> [1,3,438,906]; <F x, g> == <x, F^T g> (size-independent property)."""
+    torch.manual_seed(1)
+    for fwd, bwd in ((aa.linear_forward, aa.linear_backward), (aa.cubic_forward, aa.cubic_backward)):
+        x = torch.randn(1, 3, 438, 906, device="cuda", dtype=torch.float64)
+        g = torch.randn(1, 3, 196, 320, device="cuda", dtype=torch.float64)
+        lhs = (fwd(x, [196, 320]) * g).sum().item()
+        for atomic in (False, True):
+            rhs = (x * bwd(g, [196, 320], [1, 3, 438, 906], False, atomic=atomic)).sum().item()
+            assert abs(lhs - rhs) < 1e-9 * max(1.0, abs(lhs))
+        # fp32 against the oracle's adjoint
+        g32 = g.float()
+        exp = oracle.backward("linear" if fwd is aa.linear_forward else "cubic", g32.cpu().numpy(), (438, 906))
+        got = bwd(g32, [196, 320], [1, 3, 438, 906]).cpu().numpy()
+        np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-5)
+
+
+def test_gradcheck_fp64(aa):
+    """test.py:394-398's gradcheck (eps=1e-8 there is below fp64 resolution for this op; 1e-6 is used) on the
+    [1,2,12,17] -> [5,7] shape of SURVEY §8d(5), through torch.ops + registered autograd."""
+    from torch.autograd import gradcheck
+
+    for op in (torch.ops.extension_interpolate.linear_forward, torch.ops.extension_interpolate.cubic_forward,
+               torch.ops.extension_interpolate.nearest_forward):
+        x = torch.rand(1, 2, 12, 17, device="cuda", dtype=torch.float64, requires_grad=True)
+        assert gradcheck(lambda t: op(t, [5, 7], False), (x,), eps=1e-6, atol=1e-6, rtol=1e-6, check_batched_grad=False)
+        xu = torch.rand(1, 2, 6, 5, device="cuda", dtype=torch.float64, requires_grad=True)
+        assert gradcheck(lambda t: op(t, [9, 11], False), (xu,), eps=1e-6, atol=1e-6, rtol=1e-6, check_batched_grad=False)
+
+
+def test_backward_shape_errors(aa):
+    g = torch.zeros(1, 3, 5, 7, device="cuda")
+    with pytest.raises(RuntimeError, match="Expected grad_output to have the same shape as output"):
+        aa.linear_backward(g, [5, 8], [1, 3, 12, 17])
+    with pytest.raises(RuntimeError, match="dimension 4"):
+        aa.linear_backward(g[0], [5, 7], [1, 3, 12, 17])
+
+
+def test_native_library_is_what_ran(aa):
+    """The HIP extension, not a fallback: the .so is mapped into this process and reports its variant."""
+    from interpolate_antialiasing_amd import _lib
+
+    x = torch.rand(1, 3, 20, 20, device="cuda")
+    aa.linear_forward(x, [7, 9])
+    assert _lib.last_variant() != "none"
+    with open("/proc/self/maps") as f:
+        assert "libaa_interp.so" in f.read()
