@@ -25,7 +25,7 @@ ERR_BAD_DTYPE = -2
 EXPORTS = (
     "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build",
     "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_workspace_bytes", "aa_resample_fwd",
-    "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_last_variant",
+    "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_set_fused", "aa_last_variant",
 )
 
 
@@ -92,6 +92,8 @@ def load() -> ctypes.CDLL:
     L.aa_workspace_bytes_bwd.argtypes = [i32, i32, i64, i64, i64, i64, i64, i64]
     L.aa_workspace_bytes_bwd.restype = sz
     L.aa_last_variant.restype = ctypes.c_char_p
+    L.aa_set_fused.argtypes = [i32]
+    L.aa_set_fused.restype = i32
     if L.aa_abi_version() != 1:
         raise AAInterpError("libaa_interp.so ABI version mismatch")
     _lib = L
@@ -108,6 +110,11 @@ def check(rc: int, what: str = "") -> None:
         if rc == ERR_BAD_DTYPE:
             raise NotImplementedError(msg)
         raise AAInterpError(msg)
+
+
+def set_fused(enabled: bool) -> bool:
+    """Enable/disable the fused kernels (process-wide); returns the previous setting."""
+    return bool(load().aa_set_fused(int(bool(enabled))))
 
 
 def last_variant() -> str:

@@ -9,6 +9,7 @@
 namespace {
 
 thread_local const char *g_last_variant = "none";
+int g_fused_enabled = 1;
 
 int interp_size_of(int filter) {
   switch (filter) {
@@ -166,8 +167,10 @@ size_t aa_workspace_bytes(int dtype, int layout, int64_t N, int64_t C, int64_t H
                           const aa_axis *ax_h, const aa_axis *ax_w) {
   (void)oH;
   if (!ax_h || !ax_w || N <= 0) return 0;
-  if (aa_fused_u8_nhwc_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
-  if (aa_fused_float_nchw_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
+  if (g_fused_enabled) {
+    if (aa_fused_u8_nhwc_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
+    if (aa_fused_float_nchw_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
+  }
   return aa_generic_workspace_bytes(dtype, ax_w->kind, N, C, H, oW);
 }
 
@@ -197,8 +200,11 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
   p.stream = (hipStream_t)stream;
 
   const char *variant = "none";
-  rc = aa_try_fused_u8_nhwc(p, &variant);
-  if (rc == 0) rc = aa_try_fused_float_nchw(p, &variant);
+  rc = 0;
+  if (g_fused_enabled) {
+    rc = aa_try_fused_u8_nhwc(p, &variant);
+    if (rc == 0) rc = aa_try_fused_float_nchw(p, &variant);
+  }
   if (rc < 0) return rc;
   if (rc == 1) {
     g_last_variant = variant;
@@ -255,6 +261,12 @@ int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *wo
   p.ah = *ax_h; p.aw = *ax_w;
   p.stream = (hipStream_t)stream;
   return aa_launch_bwd_atomic(p);
+}
+
+int aa_set_fused(int enabled) {
+  const int prev = g_fused_enabled;
+  g_fused_enabled = enabled ? 1 : 0;
+  return prev;
 }
 
 const char *aa_last_variant(void) { return g_last_variant; }

@@ -26,8 +26,11 @@ __device__ inline S filt_cubic(S x) {
   const double a = -0.5;
   if (x < 0.0) x = -x;
   const double xd = (double)x;
+  // first branch: the double literals promote every operation to double
   if (x < 1.0) return (S)(((a + 2.0) * xd - (a + 3.0)) * xd * xd + 1);
-  if (x < 2.0) return (S)((((xd - 5) * xd + 8) * xd - 4) * a);
+  // second branch: `(((x - 5) * x + 8) * x - 4)` has only scalar_t and int operands, so the reference evaluates it
+  // in scalar_t (float for float tensors); only the final `* a` is a double product
+  if (x < 2.0) return (S)((double)(((x - (S)5) * x + (S)8) * x - (S)4) * a);
   return (S)0.0;
 }
 template <typename S>
