@@ -69,6 +69,18 @@ int check_dtype_kind(int dtype, int kh, int kw) {
 
 }  // namespace
 
+int aa_device_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 extern "C" {
 
 int aa_abi_version(void) { return AA_INTERP_ABI_VERSION; }

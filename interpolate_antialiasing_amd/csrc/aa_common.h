@@ -71,5 +71,7 @@ int aa_try_fused_u8_nhwc(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw(const AAProblem &p, const char **variant);
 bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
+// CU count of the current device (cached); 256 on MI355X
+int aa_device_cu_count();
 // scatter-add adjoint
 int aa_launch_bwd_atomic(const AAProblem &p);

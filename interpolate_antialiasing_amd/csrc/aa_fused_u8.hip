@@ -20,6 +20,9 @@
 //     write-after-read hazard impossible (see ring_rows in the launcher).
 // No MFMA: this is a gather-weighted-sum with ~2.3 MAC per input byte, HBM-bound by design.
 
+#include <math.h>
+#include <stdlib.h>
+
 #include "aa_common.h"
 
 namespace {
@@ -37,7 +40,8 @@ struct FusedU8Params {
   int ksize_w, ksize_h;
   int ybands, xbands;
   int bw;         // output columns per x band (multiple of 4)
-  int ring_mask;  // ring rows - 1 (power of two)
+  int ring_rows;        // LDS ring depth in rows (any value >= the hazard bound computed by the launcher)
+  unsigned ring_magic;  // floor(2^32 / ring_rows) + 1: slot(r) = r - ring_rows * mulhi(r, magic), exact for r < 2^20
   int pitch;      // LDS bytes per ring row (multiple of 16)
   unsigned long long img_in_bytes, img_out_bytes, total_in_bytes;
 };
@@ -130,6 +134,10 @@ fused_u8_nhwc_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, 
   const unsigned lane_off = (unsigned)(img_off - base_off) + (unsigned)start * C;
   const unsigned row_bytes = (unsigned)p.W * C;
   uint8_t *const ring_lane = ring + tid * C;
+  // wave-uniform ring slot of input row r (scalar multiply-high; rows are < 2^20)
+  auto slot_of = [&](int r) -> int {
+    return r - p.ring_rows * (int)__umulhi((unsigned)r, p.ring_magic);
+  };
   const int nd = (bw * C) >> 2;
   unsigned *const out_img = (unsigned *)(out + (unsigned long long)n * p.img_out_bytes) + tid;
 
@@ -172,7 +180,7 @@ fused_u8_nhwc_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, 
                 acc[c] += px * wreg[j];
               }
             }
-            uint8_t *dst = ring_lane + (size_t)((r + i) & p.ring_mask) * p.pitch;
+            uint8_t *dst = ring_lane + (size_t)slot_of(r + i) * p.pitch;
             if constexpr (C == 4) {
               *(unsigned *)dst = pack4_clip8(acc[0], acc[1], acc[2], acc[3]);
             } else if constexpr (C == 3) {
@@ -203,7 +211,7 @@ fused_u8_nhwc_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, 
         for (int j = 0; j < ys; j++) {
           int w = __builtin_amdgcn_readfirstlane(wrow[j]);
           w = (w << 8) >> 8;
-          const unsigned dw = *(const unsigned *)(ring + (size_t)((ym + j) & p.ring_mask) * p.pitch + 4 * tid);
+          const unsigned dw = *(const unsigned *)(ring + (size_t)slot_of(ym + j) * p.pitch + 4 * tid);
           a0 += (int)(dw & 0xffu) * w;
           a1 += (int)((dw >> 8) & 0xffu) * w;
           a2 += (int)((dw >> 16) & 0xffu) * w;
@@ -219,11 +227,12 @@ fused_u8_nhwc_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, 
 }
 
 constexpr int kRowsPerBarrier = 4;  // K
-constexpr int kRowsInFlight = 4;    // RB
+// RB: input rows whose window loads are in flight per lane before the first is consumed
+constexpr int rows_in_flight(int tw) { return tw <= 4 ? 8 : (tw <= 6 ? 6 : (tw <= 8 ? 4 : 2)); }
 
 template <int C, int TW>
 int launch(const FusedU8Params &p, int block, size_t lds, int64_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL((fused_u8_nhwc_kernel<C, TW, kRowsPerBarrier, (TW <= 8 ? kRowsInFlight : 2)>), dim3((unsigned)grid),
+  hipLaunchKernelGGL((fused_u8_nhwc_kernel<C, TW, kRowsPerBarrier, rows_in_flight(TW)>), dim3((unsigned)grid),
                      dim3(block), lds, stream, p.in, p.out, p.tab_w, p.tab_h, p);
   AA_HIP_CHECK_LAUNCH();
   return 1;
@@ -295,21 +304,46 @@ int aa_try_fused_u8_nhwc(const AAProblem &q, const char **variant) {
   bw = (bw + 3) & ~3;
   xbands = (int)((q.oW + bw - 1) / bw);
   const int block = ((bw + 63) / 64) * 64;
-  // row bands: enough workgroups to fill 256 CUs several times over, but keep the ~taps_h-row halo that each
-  // extra band re-reads small (>= 8 output rows per band)
-  const int64_t target_blocks = 2048;
-  int64_t ybands = (target_blocks + q.N * xbands - 1) / (q.N * xbands);
-  const int64_t max_yb = q.oH / 8 > 1 ? q.oH / 8 : 1;
-  if (ybands > max_yb) ybands = max_yb;
-  if (ybands < 1) ybands = 1;
   // ring depth: while slow waves still read chunk i's rows [ymin(first oy of chunk i), r_end(i)), fast waves may
-  // already write chunk i+1's rows [r_end(i), r_end(i+1)): span <= taps_h + 2*K*(ceil(scale_h)+1); power of two
+  // already write chunk i+1's rows [r_end(i), r_end(i+1)): span <= taps_h + 2*K*max(scale_h,1) (+ rounding slack)
   const double scale_h = (double)q.H / (double)q.oH;
-  const int ring_rows = next_pow2(taps_h + (int)(2.0 * kRowsPerBarrier * (scale_h > 1.0 ? scale_h : 1.0) + 0.999) + 4);
-  p.ring_mask = ring_rows - 1;
+  const int ring_rows = taps_h + (int)(2.0 * kRowsPerBarrier * (scale_h > 1.0 ? scale_h : 1.0) + 0.999) + 4;
+  p.ring_rows = ring_rows;
+  p.ring_magic = (unsigned)(0x100000000ull / (unsigned)ring_rows) + 1u;
+  if (q.H >= (1 << 20)) return 0;
   p.pitch = ((bw * C + 15) / 16) * 16;
   const size_t lds = (size_t)ring_rows * p.pitch;
   if (lds > 64 * 1024) return 0;
+
+  // row bands.  Every extra band re-reads and re-filters ~taps_h halo rows, but the grid must fill the chip's
+  // resident-workgroup slots a near-integer number of times or the last partial round idles most CUs
+  // (2048 workgroups on 1280 slots ran 2 rounds for 1.6 rounds of work).  Pick the band count minimising
+  // (1 + halo fraction) / round efficiency.
+  const int cus = aa_device_cu_count();
+  const int waves_per_block = block / 64;
+  int blocks_per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+  if (blocks_per_cu > 32 / waves_per_block) blocks_per_cu = 32 / waves_per_block;
+  if (blocks_per_cu > 8) blocks_per_cu = 8;
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  const double slots = (double)cus * blocks_per_cu;
+  const int64_t max_yb = q.oH / 8 > 1 ? q.oH / 8 : 1;
+  int64_t ybands = 1;
+  double best = 1e30;
+  for (int64_t yb = 1; yb <= max_yb && yb <= 64; yb++) {
+    const double items = (double)q.N * xbands * yb;
+    const double rounds = items / slots;
+    const double eff = rounds / ceil(rounds);
+    const double halo = 1.0 + (double)(yb - 1) * taps_h / (double)q.H;
+    const double cost = halo / eff;
+    if (cost < best - 1e-9) {
+      best = cost;
+      ybands = yb;
+    }
+  }
+  if (const char *e = getenv("AA_FUSED_YBANDS")) {  // tuning knob for experiments; not used by tests or bench
+    const int64_t v = atoll(e);
+    if (v >= 1 && v <= max_yb) ybands = v;
+  }
   p.ybands = (int)ybands;
   p.xbands = xbands;
   p.bw = bw;
