@@ -112,9 +112,9 @@ def check(rc: int, what: str = "") -> None:
         raise AAInterpError(msg)
 
 
-def set_fused(enabled: bool) -> bool:
+def set_fused(enabled: int) -> int:
     """Enable/disable the fused kernels (process-wide); returns the previous setting."""
-    return bool(load().aa_set_fused(int(bool(enabled))))
+    return int(load().aa_set_fused(int(enabled)))
 
 
 def last_variant() -> str:

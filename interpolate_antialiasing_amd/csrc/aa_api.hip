@@ -214,7 +214,8 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
   const char *variant = "none";
   rc = 0;
   if (g_fused_enabled) {
-    rc = aa_try_fused_u8_nhwc(p, &variant);
+    if (g_fused_enabled == 1) rc = aa_try_fused_u8_nhwc_v2(p, &variant);
+    if (rc == 0) rc = aa_try_fused_u8_nhwc(p, &variant);
     if (rc == 0) rc = aa_try_fused_float_nchw(p, &variant);
   }
   if (rc < 0) return rc;
@@ -277,7 +278,7 @@ int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *wo
 
 int aa_set_fused(int enabled) {
   const int prev = g_fused_enabled;
-  g_fused_enabled = enabled ? 1 : 0;
+  g_fused_enabled = enabled < 0 ? 0 : (enabled > 2 ? 1 : enabled);  // 0 generic, 1 auto, 2 first-generation fused only
   return prev;
 }
 

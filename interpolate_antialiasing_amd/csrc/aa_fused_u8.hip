@@ -79,13 +79,15 @@ __device__ inline unsigned pack4_clip8(int a0, int a1, int a2, int a3) {
   return d;
 }
 
-// K output rows per barrier; RB input rows of loads in flight per lane
-template <int C, int TW, int K, int RB>
+// K output rows per barrier; RB input rows of loads in flight per lane.
+// UA: byte-unaligned window loads (NV dwords straight at the window's byte offset; correct and ~1.16x faster than
+// aligned loads + v_alignbyte on gfx950 / ROCm 7.2, scratch/test_unaligned.hip) vs dword-aligned loads + alignbyte.
+template <int C, int TW, int K, int RB, bool UA>
 __global__ void __launch_bounds__(1024, 8)
 fused_u8_nhwc_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const char *__restrict__ tab_w,
                      const char *__restrict__ tab_h, const FusedU8Params p) {
   constexpr int NV = (C * TW + 3) / 4;  // aligned dwords holding the window
-  constexpr int NDW = NV + 1;           // dwords fetched (window may start at byte 1..3 of the first)
+  constexpr int NDW = UA ? NV : NV + 1;  // dwords fetched (aligned loads may start 1..3 bytes before the window)
   extern __shared__ __attribute__((aligned(16))) uint8_t ring[];
 
   const int tid = threadIdx.x;
@@ -158,7 +160,7 @@ fused_u8_nhwc_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, 
         for (int i = 0; i < RB; i++) {
           if (r + i < r_end) {
             const unsigned off = lane_off + (unsigned)(r + i) * row_bytes;
-            load_window<NDW>(rsrc, off & ~3u, d[i]);
+            load_window<NDW>(rsrc, UA ? off : (off & ~3u), d[i]);
           }
         }
 #pragma unroll
@@ -166,8 +168,13 @@ fused_u8_nhwc_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, 
           if (r + i < r_end) {
             const unsigned sh = (lane_off + (unsigned)(r + i) * row_bytes) & 3u;
             unsigned v[NV];
+            if constexpr (UA) {
 #pragma unroll
-            for (int k = 0; k < NV; k++) v[k] = __builtin_amdgcn_alignbyte(d[i][k + 1], d[i][k], sh);
+              for (int k = 0; k < NV; k++) v[k] = d[i][k];
+            } else {
+#pragma unroll
+              for (int k = 0; k < NV; k++) v[k] = __builtin_amdgcn_alignbyte(d[i][k + 1], d[i][k], sh);
+            }
             int acc[C];
 #pragma unroll
             for (int c = 0; c < C; c++) acc[c] = 1 << 21;
@@ -232,8 +239,13 @@ constexpr int rows_in_flight(int tw) { return tw <= 4 ? 8 : (tw <= 6 ? 6 : (tw <
 
 template <int C, int TW>
 int launch(const FusedU8Params &p, int block, size_t lds, int64_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL((fused_u8_nhwc_kernel<C, TW, kRowsPerBarrier, rows_in_flight(TW)>), dim3((unsigned)grid),
-                     dim3(block), lds, stream, p.in, p.out, p.tab_w, p.tab_h, p);
+  static const bool aligned_only = getenv("AA_FUSED_ALIGNED_LOADS") != nullptr;  // A/B knob
+  if (aligned_only)
+    hipLaunchKernelGGL((fused_u8_nhwc_kernel<C, TW, kRowsPerBarrier, rows_in_flight(TW), false>), dim3((unsigned)grid),
+                       dim3(block), lds, stream, p.in, p.out, p.tab_w, p.tab_h, p);
+  else
+    hipLaunchKernelGGL((fused_u8_nhwc_kernel<C, TW, kRowsPerBarrier, rows_in_flight(TW), true>), dim3((unsigned)grid),
+                       dim3(block), lds, stream, p.in, p.out, p.tab_w, p.tab_h, p);
   AA_HIP_CHECK_LAUNCH();
   return 1;
 }
