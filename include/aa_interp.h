@@ -73,8 +73,15 @@ typedef struct aa_table_header {
   int32_t align_corners;
   int32_t max_taps;      /* max_i xsize[i], filled by the device kernel */
   int32_t transposed;    /* 1 for an adjoint (backward) table built by aa_table_transpose */
-  int32_t reserved[7];
+  int32_t scatter_off;   /* AA_TABLE_PIL: byte offset of the scatter section (0 = none), see below */
+  int32_t scatter_ksize; /* row pitch of the scatter weights */
+  int32_t scatter_max;   /* max outputs fed by one input index, filled by the device kernel */
+  int32_t reserved[4];
 } aa_table_header;
+/* Scatter section (AA_TABLE_PIL tables only), used by the fused kernels whose vertical pass runs in registers:
+ * one 32-byte record per INPUT index x: { int32 first, int32 count, int32 w[6] } = the contiguous range of outputs
+ * first .. first+count-1 whose window holds x and the fixed-point weight each gives it
+ * (w[k] = weight[first+k][x - xmin[first+k]], zero padded).  Present only when count <= 6 everywhere. */
 
 /* Host-side description of one axis handed to the resample calls. */
 typedef struct aa_axis {
@@ -85,6 +92,10 @@ typedef struct aa_axis {
   int32_t max_taps;      /* from aa_table_query(); 0 = unknown (kernels then use ksize) */
   int32_t kind;          /* aa_table_kind */
   int32_t filter;        /* aa_filter */
+  int32_t scatter_off;   /* from the table header (aa_table_query); 0 = no scatter section */
+  int32_t scatter_ksize;
+  int32_t scatter_max;
+  int32_t reserved;
 } aa_axis;
 
 /* Version / diagnostics. */
@@ -97,8 +108,10 @@ int aa_device_count(void);
  * Pillow's for AA_TABLE_PIL.  scale<=0: scale derived from sizes (area_pixel_compute_scale, call site
  * s2.2:314-315).  Returns ksize (>0) or a negative aa_status. */
 int aa_table_ksize(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale);
-/* Bytes of the packed table for (kind, out_size, ksize). */
+/* Bytes of the packed table for (kind, out_size, ksize) without a scatter section (transposed tables). */
 size_t aa_table_bytes(int kind, int64_t out_size, int ksize);
+/* Bytes aa_table_build() needs for this table (AA_TABLE_PIL tables carry a scatter section as well). */
+size_t aa_table_build_bytes(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale);
 
 /* Build a packed table ON DEVICE (one thread per output index).  Asynchronous on `stream`. */
 int aa_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
@@ -148,7 +161,7 @@ int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *wo
 size_t aa_workspace_bytes_bwd(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, int64_t oH, int64_t oW);
 
 /* Kernel selection, process-wide; returns the previous setting.  1 (default): fused single-launch kernels, newest
- * design first; 2: only the first-generation fused kernels (A/B measurements); 0: none.
+ * design first; 2: first-generation fused kernels only, 3: second generation first (A/B measurements); 0: none.
  * With 0 every call takes the generic two-launch path — used by tests to cross-check the fused kernels against an
  * independent implementation at sizes the CPU oracle cannot reach, and by bench.py for A/B numbers. */
 int aa_set_fused(int enabled);

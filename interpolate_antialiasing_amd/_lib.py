@@ -23,7 +23,7 @@ ERR_BAD_DTYPE = -2
 
 # every symbol include/aa_interp.h declares (tests check the .so exports exactly these)
 EXPORTS = (
-    "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build",
+    "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build_bytes", "aa_table_build",
     "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_workspace_bytes", "aa_resample_fwd",
     "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_set_fused", "aa_last_variant",
 )
@@ -33,7 +33,8 @@ class TableHeader(ctypes.Structure):
     _fields_ = [
         ("magic", ctypes.c_int32), ("filter", ctypes.c_int32), ("kind", ctypes.c_int32), ("in_size", ctypes.c_int32),
         ("out_size", ctypes.c_int32), ("ksize", ctypes.c_int32), ("align_corners", ctypes.c_int32),
-        ("max_taps", ctypes.c_int32), ("transposed", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7),
+        ("max_taps", ctypes.c_int32), ("transposed", ctypes.c_int32), ("scatter_off", ctypes.c_int32),
+        ("scatter_ksize", ctypes.c_int32), ("scatter_max", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4),
     ]
 
 
@@ -41,6 +42,8 @@ class Axis(ctypes.Structure):
     _fields_ = [
         ("table_dev", ctypes.c_void_p), ("in_size", ctypes.c_int32), ("out_size", ctypes.c_int32),
         ("ksize", ctypes.c_int32), ("max_taps", ctypes.c_int32), ("kind", ctypes.c_int32), ("filter", ctypes.c_int32),
+        ("scatter_off", ctypes.c_int32), ("scatter_ksize", ctypes.c_int32), ("scatter_max", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -73,6 +76,8 @@ def load() -> ctypes.CDLL:
     L.aa_table_ksize.restype = i32
     L.aa_table_bytes.argtypes = [i32, i64, i32]
     L.aa_table_bytes.restype = sz
+    L.aa_table_build_bytes.argtypes = [i32, i32, i64, i64, i32, dbl]
+    L.aa_table_build_bytes.restype = sz
     L.aa_table_build.argtypes = [i32, i32, i64, i64, i32, dbl, vp, sz, vp]
     L.aa_table_build.restype = i32
     L.aa_table_transposed_ksize.argtypes = [i32, i32, i64, i64, i32, dbl]

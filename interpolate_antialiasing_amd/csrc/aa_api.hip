@@ -83,6 +83,8 @@ int aa_device_cu_count() {
 
 extern "C" {
 
+size_t aa_table_build_bytes(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale);
+
 int aa_abi_version(void) { return AA_INTERP_ABI_VERSION; }
 
 const char *aa_strerror(int status) {
@@ -125,14 +127,35 @@ size_t aa_table_bytes(int kind, int64_t out_size, int ksize) {
   return aa_table_total_bytes(kind, out_size, ksize);
 }
 
+static int scatter_ksize_for(int filter, int kind, int64_t in_size, int64_t out_size) {
+  if (kind != AA_TABLE_PIL) return 0;
+  // an input index lies in the windows of about 2*support/scale outputs; +3 covers the rounding of both window ends
+  const double s = (double)in_size / (double)out_size;
+  const double fs = filter == AA_FILTER_LINEAR ? 1.0 : (filter == AA_FILTER_CUBIC ? 2.0 : 0.5);
+  const double support = fs * (s < 1.0 ? 1.0 : s);
+  int tk = (int)ceil((2.0 * support + 1.0) / s) + 3;
+  if (tk > out_size) tk = (int)out_size;
+  if (tk < 1) tk = 1;
+  if (tk > 6) return 0;  // records hold 6 weights; wider fan-out (up-scaling) has no scatter section: the fused
+                         // in-register vertical pass does not apply there anyway
+  return 6;
+}
+
+size_t aa_table_build_bytes(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale) {
+  const int k = aa_table_ksize(filter, kind, in_size, out_size, align_corners, scale);
+  if (k < 0) return 0;
+  return aa_table_total_bytes(kind, out_size, k) + aa_table_scatter_bytes(in_size, scatter_ksize_for(filter, kind, in_size, out_size));
+}
+
 int aa_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
                    void *table_dev, size_t table_bytes, aa_stream_t stream) {
   const int k = aa_table_ksize(filter, kind, in_size, out_size, align_corners, scale);
   if (k < 0) return k;
   if (!table_dev) return AA_ERR_NULL;
-  if (table_bytes < aa_table_total_bytes(kind, out_size, k)) return AA_ERR_WORKSPACE;
+  const int sk = scatter_ksize_for(filter, kind, in_size, out_size);
+  if (table_bytes < aa_table_total_bytes(kind, out_size, k) + aa_table_scatter_bytes(in_size, sk)) return AA_ERR_WORKSPACE;
   return aa_launch_table_build(filter, kind, in_size, out_size, align_corners,
-                               scale_for(kind, in_size, out_size, align_corners, scale), k, table_dev,
+                               scale_for(kind, in_size, out_size, align_corners, scale), k, sk, table_dev,
                                (hipStream_t)stream);
 }
 
@@ -214,7 +237,8 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
   const char *variant = "none";
   rc = 0;
   if (g_fused_enabled) {
-    if (g_fused_enabled == 1) rc = aa_try_fused_u8_nhwc_v2(p, &variant);
+    if (g_fused_enabled == 1) rc = aa_try_fused_u8_nhwc_v3(p, &variant);
+    if (rc == 0 && g_fused_enabled == 3) rc = aa_try_fused_u8_nhwc_v2(p, &variant);
     if (rc == 0) rc = aa_try_fused_u8_nhwc(p, &variant);
     if (rc == 0) rc = aa_try_fused_float_nchw(p, &variant);
   }
@@ -278,7 +302,8 @@ int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *wo
 
 int aa_set_fused(int enabled) {
   const int prev = g_fused_enabled;
-  g_fused_enabled = enabled < 0 ? 0 : (enabled > 2 ? 1 : enabled);  // 0 generic, 1 auto, 2 first-generation fused only
+  // 0 generic two-pass, 1 auto (newest fused design first), 2 first-generation fused only, 3 second-generation first
+  g_fused_enabled = (enabled < 0 || enabled > 3) ? 1 : enabled;
   return prev;
 }
 

@@ -48,7 +48,11 @@ __host__ __device__ inline TableView<WT> make_table_view(const void *table, int 
 
 // entry points implemented in the .hip files and called from aa_api.cpp
 int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
-                          int ksize, void *table_dev, hipStream_t stream);
+                          int ksize, int scatter_ksize, void *table_dev, hipStream_t stream);
+// bytes of the scatter section appended to AA_TABLE_PIL tables (0 when scatter_ksize == 0)
+__host__ __device__ inline size_t aa_table_scatter_bytes(int64_t in_size, int scatter_ksize) {
+  return scatter_ksize > 0 ? 32 * (size_t)in_size : 0;  // one 8-int record per input index
+}
 int aa_launch_table_transpose(const aa_table_header &h, const void *table_dev, void *tr_dev, int tr_ksize,
                               hipStream_t stream);
 
@@ -70,6 +74,7 @@ size_t aa_generic_workspace_bytes(int dtype, int kind_w, int64_t N, int64_t C, i
 int aa_try_fused_u8_nhwc(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw(const AAProblem &p, const char **variant);
 int aa_try_fused_u8_nhwc_v2(const AAProblem &p, const char **variant);  // LDS-DMA staged, wave-specialised
+int aa_try_fused_u8_nhwc_v3(const AAProblem &p, const char **variant);  // LDS-DMA staged, wave-autonomous, V pass in registers
 bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 // CU count of the current device (cached); 256 on MI355X

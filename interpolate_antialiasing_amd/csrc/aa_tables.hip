@@ -161,16 +161,14 @@ __global__ void table_write_header(aa_table_header h, char *table) {
 // xmin[] and xmin[]+xsize[] are non-decreasing.  tmin[x] = first such output, tsize[x] = their count,
 // tw[x][k] = w[tmin+k][x - xmin[tmin+k]].
 template <typename WT>
-__global__ void table_transpose_kernel(const char *fwd, char *tr, int in_size, int out_size, int ksize, int tr_ksize) {
+__global__ void table_transpose_kernel(const char *fwd, int32_t *tmin, int32_t *tsize, WT *tw_all, int32_t *max_taps,
+                                       int in_size, int out_size, int ksize, int tr_ksize) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= in_size) return;
   const int32_t *xmin = (const int32_t *)(fwd + aa_table_xmin_off());
   const int32_t *xsize = (const int32_t *)(fwd + aa_table_xsize_off(out_size));
   const WT *w = (const WT *)(fwd + aa_table_w_off(out_size));
-  int32_t *tmin = (int32_t *)(tr + aa_table_xmin_off());
-  int32_t *tsize = (int32_t *)(tr + aa_table_xsize_off(in_size));
-  WT *tw = (WT *)(tr + aa_table_w_off(in_size)) + (size_t)x * tr_ksize;
-  int32_t *max_taps = &((aa_table_header *)tr)->max_taps;
+  WT *tw = tw_all + (size_t)x * tr_ksize;
 
   // lo = first o with xmin[o] + max(xsize[o],1) > x
   int lo = 0, hi = out_size;
@@ -200,10 +198,42 @@ __global__ void table_transpose_kernel(const char *fwd, char *tr, int in_size, i
   atomicMax(max_taps, cnt > 1 ? cnt : 1);
 }
 
+// Scatter section of AA_TABLE_PIL tables: one 32-byte record per INPUT index x, read by the fused kernels with a
+// single s_load_dwordx8: {first output fed, number of outputs fed, weight in output first+0 .. first+5}.
+__global__ void table_scatter_kernel(const char *fwd, int32_t *rec_all, int32_t *scatter_max, int in_size, int out_size,
+                                     int ksize) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= in_size) return;
+  const int32_t *xmin = (const int32_t *)(fwd + aa_table_xmin_off());
+  const int32_t *xsize = (const int32_t *)(fwd + aa_table_xsize_off(out_size));
+  const int32_t *w = (const int32_t *)(fwd + aa_table_w_off(out_size));
+  int32_t *rec = rec_all + (size_t)x * 8;
+  int lo = 0, hi = out_size;
+  while (lo < hi) {  // first o with xmin[o] + max(xsize[o],1) > x
+    const int mid = (lo + hi) >> 1;
+    const int xs = xsize[mid] > 1 ? xsize[mid] : 1;
+    if (xmin[mid] + xs > x) hi = mid; else lo = mid + 1;
+  }
+  const int first = lo;
+  lo = first; hi = out_size;
+  while (lo < hi) {  // first o with xmin[o] > x
+    const int mid = (lo + hi) >> 1;
+    if (xmin[mid] > x) hi = mid; else lo = mid + 1;
+  }
+  const int cnt = lo - first > 0 ? lo - first : 0;
+  rec[0] = cnt > 0 ? first : 0;
+  rec[1] = cnt;
+  for (int k = 0; k < 6; k++) {
+    const int o = first + k;
+    rec[2 + k] = (k < cnt) ? w[(size_t)o * ksize + (x - xmin[o])] : 0;
+  }
+  atomicMax(scatter_max, cnt > 1 ? cnt : 1);
+}
+
 }  // namespace
 
 int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
-                          int ksize, void *table_dev, hipStream_t stream) {
+                          int ksize, int scatter_ksize, void *table_dev, hipStream_t stream) {
   aa_table_header h = {};
   h.magic = AA_TABLE_MAGIC;
   h.filter = filter;
@@ -214,6 +244,13 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
   h.align_corners = align_corners;
   h.max_taps = 0;
   h.transposed = 0;
+  h.scatter_off = 0;
+  h.scatter_ksize = 0;
+  h.scatter_max = 0;
+  if (kind == AA_TABLE_PIL && scatter_ksize > 0) {
+    h.scatter_off = (int32_t)aa_table_total_bytes(kind, out_size, ksize);
+    h.scatter_ksize = scatter_ksize;
+  }
   char *t = (char *)table_dev;
   hipLaunchKernelGGL(table_write_header, dim3(1), dim3(64), 0, stream, h, t);
   const int threads = 128;
@@ -227,6 +264,14 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
   } else {
     hipLaunchKernelGGL(table_build_pil, dim3(blocks), dim3(threads), 0, stream, filter, (int)in_size, (int)out_size, ksize,
                        t);
+    if (h.scatter_off) {
+      // scatter (adjoint-form) section for the fused kernels' in-register vertical pass: for every INPUT index the
+      // outputs it feeds and their fixed-point weights
+      const int b2 = (int)((in_size + threads - 1) / threads);
+      hipLaunchKernelGGL(table_scatter_kernel, dim3(b2), dim3(threads), 0, stream, (const char *)t,
+                         (int32_t *)(t + h.scatter_off), &((aa_table_header *)t)->scatter_max, (int)in_size, (int)out_size,
+                         ksize);
+    }
   }
   AA_HIP_CHECK_LAUNCH();
   return AA_OK;
@@ -244,12 +289,15 @@ int aa_launch_table_transpose(const aa_table_header &fh, const void *table_dev, 
   hipLaunchKernelGGL(table_write_header, dim3(1), dim3(64), 0, stream, h, t);
   const int threads = 128;
   const int blocks = (fh.in_size + threads - 1) / threads;
+  int32_t *tmin = (int32_t *)(t + aa_table_xmin_off());
+  int32_t *tsize = (int32_t *)(t + aa_table_xsize_off(fh.in_size));
+  int32_t *mt = &((aa_table_header *)t)->max_taps;
   if (fh.kind == AA_TABLE_F32) {
-    hipLaunchKernelGGL(table_transpose_kernel<float>, dim3(blocks), dim3(threads), 0, stream, (const char *)table_dev, t,
-                       fh.in_size, fh.out_size, fh.ksize, tr_ksize);
+    hipLaunchKernelGGL(table_transpose_kernel<float>, dim3(blocks), dim3(threads), 0, stream, (const char *)table_dev, tmin,
+                       tsize, (float *)(t + aa_table_w_off(fh.in_size)), mt, fh.in_size, fh.out_size, fh.ksize, tr_ksize);
   } else if (fh.kind == AA_TABLE_F64) {
-    hipLaunchKernelGGL(table_transpose_kernel<double>, dim3(blocks), dim3(threads), 0, stream, (const char *)table_dev, t,
-                       fh.in_size, fh.out_size, fh.ksize, tr_ksize);
+    hipLaunchKernelGGL(table_transpose_kernel<double>, dim3(blocks), dim3(threads), 0, stream, (const char *)table_dev, tmin,
+                       tsize, (double *)(t + aa_table_w_off(fh.in_size)), mt, fh.in_size, fh.out_size, fh.ksize, tr_ksize);
   } else {
     return AA_ERR_BAD_DTYPE;
   }

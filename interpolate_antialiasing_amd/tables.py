@@ -22,7 +22,7 @@ KIND_IDS = {"pil": _lib.TABLE_PIL, "f32": _lib.TABLE_F32, "f64": _lib.TABLE_F64}
 HEADER_BYTES = ctypes.sizeof(_lib.TableHeader)  # 64
 
 # fixed-length int64 descriptor broadcast ahead of the payload so receivers can allocate
-META_LEN = 10
+META_LEN = 13
 
 
 def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
@@ -42,17 +42,21 @@ class WeightTable:
     max_taps: int
     align_corners: bool = False
     transposed: bool = False
+    scatter_off: int = 0
+    scatter_ksize: int = 0
+    scatter_max: int = 0
 
     def axis(self) -> _lib.Axis:
         if not self.buf.is_cuda:
             raise _lib.AAInterpError("weight table is not on a GPU")
         return _lib.Axis(ctypes.c_void_p(self.buf.data_ptr()), self.in_size, self.out_size, self.ksize, self.max_taps,
-                         self.kind, self.filter)
+                         self.kind, self.filter, self.scatter_off, self.scatter_ksize, self.scatter_max, 0)
 
     # ---- transport -----------------------------------------------------------------------------------
     def meta(self) -> torch.Tensor:
         return torch.tensor([0x42544141, self.filter, self.kind, self.in_size, self.out_size, self.ksize,
-                             self.max_taps, int(self.align_corners), int(self.transposed), self.buf.numel()],
+                             self.max_taps, int(self.align_corners), int(self.transposed), self.buf.numel(),
+                             self.scatter_off, self.scatter_ksize, self.scatter_max],
                             dtype=torch.int64)
 
     @staticmethod
@@ -63,9 +67,21 @@ class WeightTable:
         if buf.numel() != m[9]:
             raise _lib.AAInterpError("weight-table payload size mismatch")
         return WeightTable(buf=buf, filter=m[1], kind=m[2], in_size=m[3], out_size=m[4], ksize=m[5], max_taps=m[6],
-                           align_corners=bool(m[7]), transposed=bool(m[8]))
+                           align_corners=bool(m[7]), transposed=bool(m[8]), scatter_off=m[10], scatter_ksize=m[11],
+                           scatter_max=m[12])
 
     # ---- inspection (tests) ----------------------------------------------------------------------------
+    def unpack_scatter(self):
+        """-> (tmin int32[in], tsize int32[in], tw int32[in, scatter_ksize]) of an AA_TABLE_PIL table (CPU numpy)."""
+        import numpy as np
+
+        if not self.scatter_off:
+            return None
+        raw = self.buf.detach().cpu().numpy()
+        n, off = self.in_size, self.scatter_off
+        rec = raw[off:off + 32 * n].view(np.int32).reshape(n, 8).copy()
+        return rec[:, 0], rec[:, 1], rec[:, 2:]
+
     def unpack(self):
         """-> (xmin int32[out], xsize int32[out], w [out,ksize]) as CPU numpy arrays."""
         import numpy as np
@@ -103,7 +119,7 @@ def build_table(filter_id: int, kind: int, in_size: int, out_size: int, align_co
     L = _lib.load()
     k = L.aa_table_ksize(filter_id, kind, in_size, out_size, int(align_corners), float(scale or 0.0))
     _lib.check(k, "aa_table_ksize")
-    nbytes = L.aa_table_bytes(kind, out_size, k)
+    nbytes = L.aa_table_build_bytes(filter_id, kind, in_size, out_size, int(align_corners), float(scale or 0.0))
     with torch.cuda.device(device):
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         s = _stream_ptr(device)
@@ -111,7 +127,8 @@ def build_table(filter_id: int, kind: int, in_size: int, out_size: int, align_co
                                     ctypes.c_void_p(buf.data_ptr()), nbytes, s), "aa_table_build")
         hdr = _lib.TableHeader()
         _lib.check(L.aa_table_query(ctypes.c_void_p(buf.data_ptr()), ctypes.byref(hdr), s), "aa_table_query")
-    return WeightTable(buf, filter_id, kind, in_size, out_size, k, int(hdr.max_taps), bool(align_corners), False)
+    return WeightTable(buf, filter_id, kind, in_size, out_size, k, int(hdr.max_taps), bool(align_corners), False,
+                       int(hdr.scatter_off), int(hdr.scatter_ksize), int(hdr.scatter_max))
 
 
 def get_table(filter_id: int, kind: int, in_size: int, out_size: int, align_corners: bool = False, scale: float = 0.0,
