@@ -193,9 +193,9 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     slot_ph[j] = (unsigned)(j * p.seg_bytes) + ph;  // uniform
     slot_ra[j] = (lane_lds + slot_ph[j]) & ~3u;      // per lane
   }
-  auto fetch = [&](unsigned a_row, int slot, unsigned (&d)[ND]) -> unsigned {
+  auto fetch = [&](unsigned a_row, int slot, unsigned (&d)[ND], bool tables = true) -> unsigned {
     unsigned sa, ra;
-    if constexpr (PERIODIC) {
+    if (PERIODIC && tables) {  // `slot` must be a compile-time constant here (register arrays)
       sa = lane_lds + slot_ph[slot];  // only its low two bits are used (v_alignbyte)
       ra = slot_ra[slot];
     } else {
@@ -299,7 +299,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   {
     const int younger = (n_rows < G ? n_rows : G) - 1;
     wait_vmcnt(younger * dma_per_row);
-    sa0 = fetch(a, 0, d0);
+    sa0 = fetch(a, 0, d0, false);
   }
   // Invariant at the top of row x (slot x % G): DMAs issued up to row x+G-1; row x's window reads issued into d0 (x
   // even) / d1 (x odd); its scatter record loaded into sc0 / sc1.  Output stores also count in vmcnt: they are
@@ -324,6 +324,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
         dma(a + (unsigned)G * row_bytes, i);  // the slot just consumed gets row x+G
         a += row_bytes;
         r++;
+        __builtin_amdgcn_sched_barrier(0);  // keep the unrolled rows from interleaving: it only costs registers
       }
     } else {
       for (int i = 0; i < G; i++) {
@@ -333,8 +334,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           int younger = n_rows - 1 - (x + 1);
           younger = younger < G - 2 ? younger : G - 2;
           wait_vmcnt(younger * dma_per_row);
-          if ((i & 1) == 0) { sc1 = load_scatter(r + 1); sa1 = fetch(a + row_bytes, (i + 1) % G, d1); }
-          else { sc0 = load_scatter(r + 1); sa0 = fetch(a + row_bytes, (i + 1) % G, d0); }
+          if ((i & 1) == 0) { sc1 = load_scatter(r + 1); sa1 = fetch(a + row_bytes, (i + 1) % G, d1, false); }
+          else { sc0 = load_scatter(r + 1); sa0 = fetch(a + row_bytes, (i + 1) % G, d0, false); }
         }
         if ((i & 1) == 0) row_step(d0, sa0, r, sc0);
         else row_step(d1, sa1, r, sc1);
@@ -348,9 +349,44 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 
 int g_group3 = 8;
 
+// Row bands: every extra band re-reads and re-filters ~taps_h halo rows, but the grid must fill the chip's resident
+// wave slots a near-integer number of times or the last partial round idles most CUs.  Pick the band count
+// minimising (1 + halo fraction) / round efficiency.
+int pick_ybands(int64_t items_per_band, double slots, int taps_h, int64_t H, int64_t oH) {
+  const int64_t max_yb = oH / 8 > 1 ? oH / 8 : 1;
+  int64_t ybands = 1;
+  double best = 1e30;
+  for (int64_t yb = 1; yb <= max_yb && yb <= 64; yb++) {
+    const double rounds = (double)items_per_band * yb / slots;
+    const double eff = rounds / ceil(rounds);
+    const double halo = 1.0 + (double)(yb - 1) * taps_h / (double)H;
+    const double cost = halo / eff;
+    if (cost < best - 1e-9) {
+      best = cost;
+      ybands = yb;
+    }
+  }
+  if (const char *e = getenv("AA_FUSED_YBANDS")) {  // experiment knob
+    const int64_t v = atoll(e);
+    if (v >= 1 && v <= max_yb) ybands = v;
+  }
+  return (int)ybands;
+}
+
 template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC>
-int launch_k(const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
-  hipLaunchKernelGGL((fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC>), dim3((unsigned)grid), dim3(64), lds,
+int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
+  auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC>;
+  static int waves_per_cu = 0;  // resident 64-thread workgroups per CU for this instantiation (registers + LDS)
+  if (waves_per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, lds) != hipSuccess || nb <= 0) nb = 16;
+    waves_per_cu = nb > 32 ? 32 : nb;
+  }
+  const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
+  p.ybands = pick_ybands(q.N * p.nstrips, (double)aa_device_cu_count() * waves_per_cu, taps_h, q.H, q.oH);
+  const int64_t grid = q.N * (int64_t)p.ybands * p.nstrips;
+  if (grid > 0x7FFFFFFF) return 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds,
                      q.stream, (const uint8_t *)q.in - p.in_mis, (uint8_t *)q.out, (const char *)q.aw.table_dev,
                      (const char *)q.ah.table_dev, p);
   AA_HIP_CHECK_LAUNCH();
@@ -446,34 +482,8 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   const size_t lds = (size_t)G * p.seg_bytes;
   if (lds > 64 * 1024) return 0;
 
-  // row bands: fill the chip's wave slots a near-integer number of times (see aa_fused_u8.hip)
-  const int cus = aa_device_cu_count();
-  int waves_per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
-  if (waves_per_cu > 32) waves_per_cu = 32;
-  if (waves_per_cu < 1) waves_per_cu = 1;
-  const double slots = (double)cus * waves_per_cu;
-  const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
-  const int64_t max_yb = q.oH / 8 > 1 ? q.oH / 8 : 1;
-  int64_t ybands = 1;
-  double best = 1e30;
-  for (int64_t yb = 1; yb <= max_yb && yb <= 64; yb++) {
-    const double items = (double)q.N * p.nstrips * yb;
-    const double rounds = items / slots;
-    const double eff = rounds / ceil(rounds);
-    const double halo = 1.0 + (double)(yb - 1) * taps_h / (double)q.H;
-    const double cost = halo / eff;
-    if (cost < best - 1e-9) {
-      best = cost;
-      ybands = yb;
-    }
-  }
-  if (const char *e = getenv("AA_FUSED_YBANDS")) {  // experiment knob
-    const int64_t v = atoll(e);
-    if (v >= 1 && v <= max_yb) ybands = v;
-  }
-  p.ybands = (int)ybands;
-  const int64_t grid = q.N * ybands * p.nstrips;
-  if (grid > 0x7FFFFFFF) return 0;
+  const int64_t grid = 0;  // decided per kernel instantiation (launch_k)
+  p.ybands = 1;
 
   const int rc = (C == 3) ? dispatch_tw<3>(tw, q.ah.scatter_max, p, q, lds, grid) : dispatch_tw<4>(tw, q.ah.scatter_max, p, q, lds, grid);
   if (rc == 1) *variant = "fused_u8_nhwc_pil_v3";
