@@ -35,6 +35,8 @@ struct FusedU8V3Params {
   int H, W, oH, oW;
   int ksize_w, ksize_h;
   int ybands, nstrips;
+  int strips_per_block;  // waves per workgroup
+  int strip_w;           // output columns per strip (<= 64, multiple of 4)
   int nseg;        // 16-byte pieces per staged row segment (<= 128)
   int seg_bytes;   // nseg * 16
   int sc_off;      // scatter section of the H table (bytes from table start): one 8-int record per input row
@@ -71,21 +73,26 @@ __device__ inline void wait_vmcnt(int n) {  // rounding n DOWN only waits longer
 //         intermediate is a plain shift.  PERIODIC: G*row_bytes is a multiple of 16, so the 16-byte phase of a staged
 //         row depends only on its stage slot and the per-slot LDS window addresses are loop invariants.
 template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(512)
 fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const char *__restrict__ tab_w,
                         const char *__restrict__ tab_h, const FusedU8V3Params p) {
   constexpr int NV = (C * TW + 3) / 4;  // dwords holding one window
   constexpr int ND = NV + 1;            // aligned dwords fetched per window
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
-  const int lane = threadIdx.x;
+  // a workgroup is the nstrips_blk independent waves (strips) of one band: no barrier, no shared LDS; they only
+  // share a CU so that the 64-byte sectors two neighbouring segments have in common come from L1/L2, not HBM
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int b = blockIdx.x;
-  const int strip = b % p.nstrips;
-  b /= p.nstrips;
+  const int sgroups = (p.nstrips + p.strips_per_block - 1) / p.strips_per_block;
+  const int strip = (b % sgroups) * p.strips_per_block + wv;
+  b /= sgroups;
+  if (strip >= p.nstrips) return;
   const int yb = b % p.ybands;
   const int n = b / p.ybands;
-  const int ox0 = strip * 64;
-  const int bw = min(64, p.oW - ox0);
+  const int ox0 = strip * p.strip_w;
+  const int bw = min(p.strip_w, p.oW - ox0);
   const int oy0 = (int)((long long)yb * p.oH / p.ybands);
   const int oy1 = (int)((long long)(yb + 1) * p.oH / p.ybands);
 
@@ -106,7 +113,6 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 
   // ---- per-lane horizontal-pass state ------------------------------------------------------------------------
   const bool active = lane < bw;
-  const bool wave_full = bw == 64;
   const int ox = ox0 + (active ? lane : 0);
   const int xm = xmin_w[ox];
   int xs = xsize_w[ox];
@@ -132,7 +138,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)(in + base_off), 0, (unsigned)remaining, 0x00020000);
   const unsigned row_bytes = (unsigned)p.W * C;
-  const unsigned lane_lds = (unsigned)c_l;
+  const int lds_base = wv * G * p.seg_bytes;  // this wave's private stage ring
+  const unsigned lane_lds = (unsigned)(lds_base + c_l);
   const bool dma_lane0 = lane < p.nseg;
   const bool dma_lane1 = lane + 64 < p.nseg;
   constexpr int dma_per_row = TWO_DMA ? 2 : 1;
@@ -177,7 +184,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 
   auto dma = [&](unsigned a_row, int slot) {
     const unsigned soff = a_row & ~15u;
-    const int dst = slot * p.seg_bytes;
+    const int dst = lds_base + slot * p.seg_bytes;
     if (dma_lane0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, soff, 0, 0);
     if constexpr (TWO_DMA) {
       if (dma_lane1)
@@ -308,7 +315,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   int r = r_begin;
   for (int g = 0; g < n_groups; g++) {
     const int x0 = g * G;
-    if (wave_full && x0 + 2 * G <= n_rows) {
+    if (x0 + 2 * G <= n_rows) {  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
 #pragma unroll
       for (int i = 0; i < G; i++) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_row * (G - 2)) : "memory");
@@ -376,17 +383,20 @@ int pick_ybands(int64_t items_per_band, double slots, int taps_h, int64_t H, int
 template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC>
 int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
   auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC>;
-  static int waves_per_cu = 0;  // resident 64-thread workgroups per CU for this instantiation (registers + LDS)
-  if (waves_per_cu == 0) {
+  const int spb = p.strips_per_block;
+  const int sgroups = (p.nstrips + spb - 1) / spb;
+  const size_t lds_blk = lds * spb;
+  static int blocks_per_cu[9] = {0};  // resident workgroups per CU for this instantiation, by waves per workgroup
+  if (blocks_per_cu[spb] == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, lds) != hipSuccess || nb <= 0) nb = 16;
-    waves_per_cu = nb > 32 ? 32 : nb;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * spb, lds_blk) != hipSuccess || nb <= 0) nb = 16 / spb;
+    blocks_per_cu[spb] = nb < 1 ? 1 : nb;
   }
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
-  p.ybands = pick_ybands(q.N * p.nstrips, (double)aa_device_cu_count() * waves_per_cu, taps_h, q.H, q.oH);
-  const int64_t grid = q.N * (int64_t)p.ybands * p.nstrips;
+  p.ybands = pick_ybands(q.N * sgroups, (double)aa_device_cu_count() * blocks_per_cu[spb], taps_h, q.H, q.oH);
+  const int64_t grid = q.N * (int64_t)p.ybands * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk,
                      q.stream, (const uint8_t *)q.in - p.in_mis, (uint8_t *)q.out, (const char *)q.aw.table_dev,
                      (const char *)q.ah.table_dev, p);
   AA_HIP_CHECK_LAUNCH();
@@ -472,6 +482,14 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   p.total_out_bytes = p.img_out_bytes * (unsigned long long)q.N;
   p.sc_off = q.ah.scatter_off;
   p.nstrips = (int)((q.oW + 63) / 64);
+  p.strip_w = (int)(((q.oW + p.nstrips - 1) / p.nstrips + 3) & ~3);  // balanced strips (196 -> 4 x 52, not 3 x 64 + 4)
+  p.nstrips = (int)((q.oW + p.strip_w - 1) / p.strip_w);
+  // all strips of a band in one workgroup when they fit (<= 8 waves); wider images: groups of 4 strips
+  p.strips_per_block = p.nstrips <= 8 ? p.nstrips : 4;
+  if (const char *e = getenv("AA_V3_SPB")) {  // experiment knob
+    const int v = atoi(e);
+    if (v >= 1 && v <= 8) p.strips_per_block = v;
+  }
 
   // segment: bytes covered by 64 consecutive windows of one input row (+ alignment slack), see aa_fused_u8_v2.hip
   const double scale_w = (double)q.W / (double)q.oW;

@@ -1,0 +1,187 @@
+"""CPU (-m "not gpu"): host logic, the C-ABI library's exports, sharding + table broadcast over gloo (world_size 2).
+No compute call needs a GPU here; nothing in the product routes through the oracle."""
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """libaa_interp.so loads without a GPU and exports exactly what include/aa_interp.h declares."""
+    from interpolate_antialiasing_amd import _lib
+
+    L = _lib.load()
+    header = open(_lib.HEADER_PATH).read()
+    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*\s*|size_t\s+|int\s+)(aa_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.aa_abi_version() == 1
+    assert L.aa_device_count() >= 0  # 0 on the CPU-only build box, never throws
+    assert _lib.strerror(-2).startswith("dtype")
+
+
+def test_ksize_host_arithmetic_matches_oracle():
+    """aa_table_ksize replicates s2.2:207-210 (and Pillow's ceil(support)*2+1) on the host."""
+    from interpolate_antialiasing_amd import _lib
+
+    L = _lib.load()
+    for filt, fid in (("linear", 0), ("cubic", 1), ("box", 2)):
+        for n_in, n_out in [(906, 320), (438, 196), (1024, 224), (438, 1200), (906, 1200), (64, 64), (61, 1), (3, 2), (5, 7)]:
+            assert L.aa_table_ksize(fid, _lib.TABLE_F32, n_in, n_out, 0, 0.0) == oracle.ksize(filt, n_in, n_out, False, np.float32)
+            assert L.aa_table_ksize(fid, _lib.TABLE_F64, n_in, n_out, 0, 0.0) == oracle.ksize(filt, n_in, n_out, False, np.float64)
+            assert L.aa_table_ksize(fid, _lib.TABLE_F32, n_in, n_out, 1, 0.0) == oracle.ksize(filt, n_in, n_out, True, np.float32)
+            assert L.aa_table_ksize(fid, _lib.TABLE_PIL, n_in, n_out, 0, 0.0) == oracle.pil_coeffs(filt, n_in, n_out)[0]
+    assert L.aa_table_ksize(7, _lib.TABLE_F32, 8, 4, 0, 0.0) == -1  # AA_ERR_BAD_FILTER
+    assert L.aa_table_ksize(0, _lib.TABLE_F32, 0, 4, 0, 0.0) == -4  # AA_ERR_BAD_SHAPE
+    assert L.aa_table_ksize(0, _lib.TABLE_PIL, 8, 4, 1, 0.0) == -2  # Pillow has no align_corners
+    # table sizes: header + bounds + padded weights (+ scatter records for Pillow tables)
+    assert L.aa_table_bytes(_lib.TABLE_F32, 320, 7) == 64 + ((8 * 320 + 15) // 16) * 16 + 320 * 7 * 4
+    assert L.aa_table_build_bytes(0, _lib.TABLE_PIL, 438, 196, 0, 0.0) == L.aa_table_bytes(_lib.TABLE_PIL, 196, 7) + 32 * 438
+
+
+def test_argument_errors_without_gpu():
+    """Same wording as ATen's upsample_2d_common_check / the reference's dispatch errors; raised before any device work."""
+    from interpolate_antialiasing_amd import _lib
+    from interpolate_antialiasing_amd import extension_interpolate as aa
+
+    x = torch.zeros(1, 3, 8, 8)
+    with pytest.raises(RuntimeError, match="Input and output sizes should be greater than 0"):
+        aa.linear_forward(x, [0, 4])
+    with pytest.raises(RuntimeError, match="It is expected input_size equals to 4"):
+        aa.cubic_forward(x[0], [4, 4])
+    with pytest.raises(RuntimeError, match="It is expected output_size equals to 2"):
+        aa.nearest_forward(x, [4, 4, 4])
+    with pytest.raises(NotImplementedError, match="not implemented for 'Half'"):
+        aa.linear_forward(x.half(), [4, 4])
+    # the product is the HIP path only: CPU tensors fail loudly, nothing falls back to a CPU implementation
+    with pytest.raises(_lib.AAInterpError, match="no CPU implementation"):
+        aa.linear_forward(x, [4, 4])
+    with pytest.raises(RuntimeError, match="Expected grad_output to have the same shape as output"):
+        aa.linear_backward(torch.zeros(1, 3, 5, 7), [5, 8], [1, 3, 12, 17])
+    with pytest.raises(_lib.AAInterpError, match="no CPU implementation"):
+        aa.linear_backward(torch.zeros(1, 3, 5, 7), [5, 7], [1, 3, 12, 17])
+    assert aa.forward is aa.linear_forward  # legacy export of every other step
+    with pytest.raises(ValueError):
+        aa.set_uint8_mode("nearest")
+    # torch.ops surface exists with the reference's names
+    for name in ("linear_forward", "nearest_forward", "cubic_forward", "linear_backward", "forward"):
+        assert hasattr(torch.ops.extension_interpolate, name)
+    # shape inference without a device
+    y = torch.ops.extension_interpolate.linear_forward(torch.zeros(2, 3, 8, 8, device="meta"), [4, 5], False)
+    assert tuple(y.shape) == (2, 3, 4, 5)
+
+
+def test_product_does_not_import_the_oracle():
+    """The package must never depend on oracle/ (a product path through the checker would void the parity claims)."""
+    pkg = os.path.join(ROOT, "interpolate_antialiasing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "liboracle" not in src and "aa_oracle" not in src, f
+
+
+def test_shard_range_partitions_exactly():
+    from interpolate_antialiasing_amd import sharding
+
+    for total in (0, 1, 7, 8, 1000, 8192):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                assert a1 == b0 and a0 <= a1
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert sharding.shard_range(8192, 3, 8) == (3072, 4096)  # config 3: 1024 images per GPU
+    with pytest.raises(ValueError):
+        sharding.shard_range(8, 2, 2)
+
+
+def _pack_table_numpy(filt, n_in, n_out):
+    """Build the packed F32 table format on the CPU from the oracle (tests only)."""
+    k, xmin, xsize, w = oracle.weights(filt, n_in, n_out, False, np.float32)
+    woff = (64 + 8 * n_out + 15) & ~15
+    buf = np.zeros(woff + 4 * n_out * k, np.uint8)
+    hdr = np.zeros(16, np.int32)
+    hdr[:9] = [0x42544141, oracle.FILTERS[filt], 1, n_in, n_out, k, 0, int(max(1, xsize.max())), 0]
+    buf[:64] = hdr.view(np.uint8)
+    buf[64:64 + 4 * n_out] = xmin.astype(np.int32).view(np.uint8)
+    buf[64 + 4 * n_out:64 + 8 * n_out] = xsize.astype(np.int32).view(np.uint8)
+    buf[woff:] = w.astype(np.float32).reshape(-1).view(np.uint8)
+    return buf, k, int(max(1, xsize.max()))
+
+
+def test_weight_table_pack_unpack_roundtrip():
+    from interpolate_antialiasing_amd import _lib
+    from interpolate_antialiasing_amd.tables import WeightTable
+
+    buf, k, mt = _pack_table_numpy("linear", 906, 320)
+    t = WeightTable(torch.from_numpy(buf), 0, _lib.TABLE_F32, 906, 320, k, mt)
+    xmin, xsize, w = t.unpack()
+    ko, xo, so, wo = oracle.weights("linear", 906, 320)
+    assert np.array_equal(xmin, xo) and np.array_equal(xsize, so) and np.array_equal(w, wo)
+    t2 = WeightTable.from_meta(t.meta(), t.buf.clone())
+    assert (t2.filter, t2.kind, t2.in_size, t2.out_size, t2.ksize, t2.max_taps) == (0, 1, 906, 320, k, mt)
+    with pytest.raises(_lib.AAInterpError):
+        t.axis()  # a CPU-resident table cannot be handed to the kernels
+
+
+_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from interpolate_antialiasing_amd import _lib, sharding
+from interpolate_antialiasing_amd.tables import WeightTable
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from test_host_cpu import _pack_table_numpy
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+# rank 0 owns the table; everyone else receives it with the single broadcast the path has
+t = None
+if rank == 0:
+    buf, k, mt = _pack_table_numpy("linear", 438, 196)
+    t = WeightTable(torch.from_numpy(buf), 0, _lib.TABLE_F32, 438, 196, k, mt)
+got = sharding.broadcast_table(t, src=0, device=torch.device("cpu"))
+ref, k, mt = _pack_table_numpy("linear", 438, 196)
+assert np.array_equal(got.buf.numpy(), ref) and got.ksize == k and got.max_taps == mt and got.in_size == 438
+# batch shard of config 3 + the bench's reductions
+a, b = sharding.shard_range(8192, rank, world)
+assert b - a == 8192 // world
+x = torch.arange(10)
+assert sharding.shard_batch(x, rank, world).tolist() == list(range(*sharding.shard_range(10, rank, world)))
+assert sharding.reduce_sum_int(b - a) == 8192
+assert abs(sharding.reduce_max_seconds(0.5 + rank) - (0.5 + world - 1)) < 1e-12
+dist.barrier()
+dist.destroy_process_group()
+print("worker", rank, "ok")
+'''
+
+
+def test_table_broadcast_and_sharding_gloo_world2(tmp_path):
+    """The N>1 path (one process per rank, table broadcast, shard, reductions) with the gloo backend on CPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"worker {rank} ok" in out
