@@ -73,12 +73,12 @@ typedef struct aa_table_header {
   int32_t align_corners;
   int32_t max_taps;      /* max_i xsize[i], filled by the device kernel */
   int32_t transposed;    /* 1 for an adjoint (backward) table built by aa_table_transpose */
-  int32_t scatter_off;   /* AA_TABLE_PIL: byte offset of the scatter section (0 = none), see below */
+  int32_t scatter_off;   /* byte offset of the scatter section (0 = none), see below */
   int32_t scatter_ksize; /* row pitch of the scatter weights */
   int32_t scatter_max;   /* max outputs fed by one input index, filled by the device kernel */
   int32_t reserved[4];
 } aa_table_header;
-/* Scatter section (AA_TABLE_PIL tables only), used by the fused kernels whose vertical pass runs in registers:
+/* Scatter section (AA_TABLE_PIL and AA_TABLE_F32 tables), used by the fused kernels whose vertical pass runs in registers:
  * one 32-byte record per INPUT index x: { int32 first, int32 count, int32 w[6] } = the contiguous range of outputs
  * first .. first+count-1 whose window holds x and the fixed-point weight each gives it
  * (w[k] = weight[first+k][x - xmin[first+k]], zero padded).  Present only when count <= 6 everywhere. */

@@ -128,17 +128,10 @@ size_t aa_table_bytes(int kind, int64_t out_size, int ksize) {
 }
 
 static int scatter_ksize_for(int filter, int kind, int64_t in_size, int64_t out_size) {
-  if (kind != AA_TABLE_PIL) return 0;
-  // an input index lies in the windows of about 2*support/scale outputs; +3 covers the rounding of both window ends
-  const double s = (double)in_size / (double)out_size;
-  const double fs = filter == AA_FILTER_LINEAR ? 1.0 : (filter == AA_FILTER_CUBIC ? 2.0 : 0.5);
-  const double support = fs * (s < 1.0 ? 1.0 : s);
-  int tk = (int)ceil((2.0 * support + 1.0) / s) + 3;
-  if (tk > out_size) tk = (int)out_size;
-  if (tk < 1) tk = 1;
-  if (tk > 6) return 0;  // records hold 6 weights; wider fan-out (up-scaling) has no scatter section: the fused
-                         // in-register vertical pass does not apply there anyway
-  return 6;
+  (void)filter; (void)in_size; (void)out_size;
+  // 32-bit weights only (a record holds 6).  Always present: whether an input index really feeds <= 6 outputs is
+  // measured by the device kernel (header.scatter_max) and the fused kernels check that before using the section.
+  return (kind == AA_TABLE_PIL || kind == AA_TABLE_F32) ? 6 : 0;
 }
 
 size_t aa_table_build_bytes(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale) {

@@ -247,7 +247,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
   h.scatter_off = 0;
   h.scatter_ksize = 0;
   h.scatter_max = 0;
-  if (kind == AA_TABLE_PIL && scatter_ksize > 0) {
+  if ((kind == AA_TABLE_PIL || kind == AA_TABLE_F32) && scatter_ksize > 0) {
     h.scatter_off = (int32_t)aa_table_total_bytes(kind, out_size, ksize);
     h.scatter_ksize = scatter_ksize;
   }
@@ -258,6 +258,12 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
   if (kind == AA_TABLE_F32) {
     hipLaunchKernelGGL(table_build_f32, dim3(blocks), dim3(threads), 0, stream, filter, (int)in_size, (int)out_size, ksize,
                        (float)scale, t);
+    if (h.scatter_off) {  // float weights travel through the 32-bit record fields bit for bit
+      const int b2 = (int)((in_size + threads - 1) / threads);
+      hipLaunchKernelGGL(table_scatter_kernel, dim3(b2), dim3(threads), 0, stream, (const char *)t,
+                         (int32_t *)(t + h.scatter_off), &((aa_table_header *)t)->scatter_max, (int)in_size, (int)out_size,
+                         ksize);
+    }
   } else if (kind == AA_TABLE_F64) {
     hipLaunchKernelGGL(table_build_f64, dim3(blocks), dim3(threads), 0, stream, filter, (int)in_size, (int)out_size, ksize,
                        scale, t);
