@@ -347,7 +347,7 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
   const int mc = q.ah.scatter_max;
   // G (rows in flight) shrinks as segments grow so that a workgroup's stage rings stay within 64 KiB
   const size_t lds8 = (size_t)8 * p.seg_bytes, lds4 = (size_t)4 * p.seg_bytes;
-  const bool g8 = lds8 * p.strips_per_block <= 48 * 1024;
+  const bool g8 = lds8 * p.strips_per_block <= 32 * 1024;
   if (tw <= 2) rc = g8 ? launch_m<2, 8>(mc, p, q, lds8) : launch_m<2, 4>(mc, p, q, lds4);
   else if (tw <= 4) rc = g8 ? launch_m<4, 8>(mc, p, q, lds8) : launch_m<4, 4>(mc, p, q, lds4);
   else if (tw <= 8) rc = g8 ? launch_m<8, 8>(mc, p, q, lds8) : launch_m<8, 4>(mc, p, q, lds4);

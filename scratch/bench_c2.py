@@ -1,0 +1,8 @@
+import sys, torch
+sys.path.insert(0, '/root/repo')
+from interpolate_antialiasing_amd import _lib, extension_interpolate as aa
+torch.manual_seed(0)
+x = torch.rand(64, 3, 1024, 1024, device='cuda') * 255
+for _ in range(4): y = aa.cubic_forward(x, [224, 224])
+torch.cuda.synchronize()
+print(_lib.last_variant())
