@@ -134,7 +134,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   const unsigned long long img_off = (unsigned long long)p.in_mis + (unsigned long long)n * p.img_in_bytes;
   const unsigned long long base_off = img_off & ~15ull;
   unsigned long long remaining = p.total_in_bytes - base_off;
-  if (remaining > 0xFFFFFFFFull) remaining = 0xFFFFFFFFull;
+  remaining = (remaining + 3ull) & ~3ull;  // the range check works per dword: serve the last, partial one too
+  if (remaining > 0xFFFFFFFCull) remaining = 0xFFFFFFFCull;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)(in + base_off), 0, (unsigned)remaining, 0x00020000);
   const unsigned row_bytes = (unsigned)p.W * C;

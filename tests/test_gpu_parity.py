@@ -168,7 +168,9 @@ def test_u8_headline_config_pil_parity(aa, golden_kat):
 
 @pytest.mark.parametrize("shape,size", [((5, 3, 438, 906), (196, 320)), ((3, 3, 906, 438), (320, 196)), ((2, 4, 50, 70), (31, 22)),
                                         ((2, 1, 33, 47), (66, 20)), ((1, 3, 1024, 1024), (224, 224)), ((2, 3, 100, 37), (100, 90)),
-                                        ((7, 3, 64, 64), (1, 1)), ((1, 2, 5, 4), (40, 33))])
+                                        ((7, 3, 64, 64), (1, 1)), ((1, 2, 5, 4), (40, 33)),
+                                        # byte counts that are not multiples of 4 / 16 on the fused paths (range-checked tails)
+                                        ((1, 3, 33, 37), (15, 16)), ((3, 3, 35, 41), (17, 20)), ((2, 4, 31, 29), (9, 11))])
 def test_u8_random_vs_oracle(aa, shape, size):
     rng = np.random.default_rng(hash((shape, size)) % (2**32))
     x = rng.integers(0, 256, shape, dtype=np.uint8)
@@ -305,3 +307,71 @@ def test_native_library_is_what_ran(aa):
     assert _lib.last_variant() != "none"
     with open("/proc/self/maps") as f:
         assert "libaa_interp.so" in f.read()
+
+
+# ------------------------------------------------------------------------------------------------ fused vs generic
+def test_fused_kernels_match_generic_at_full_size(aa):
+    """Two independent implementations (fused single-launch vs generic two-launch) must agree bit for bit at
+    BASELINE sizes, where the CPU oracle is too slow to be the checker for whole batches."""
+    from interpolate_antialiasing_amd import _lib
+
+    torch.manual_seed(3)
+    cases = []
+    x8 = torch.randint(0, 256, (48, 438, 906, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
+    cases += [(aa.linear_forward, x8, [196, 320]), (aa.cubic_forward, x8, [196, 320]), (aa.nearest_forward, x8, [196, 320])]
+    x8t = torch.randint(0, 256, (16, 906, 438, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)  # config 3 shape
+    cases += [(aa.linear_forward, x8t, [320, 196])]
+    x4 = torch.randint(0, 256, (5, 300, 500, 4), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)   # C = 4
+    cases += [(aa.linear_forward, x4, [111, 204]), (aa.cubic_forward, x4, [150, 252])]
+    xf = torch.rand(6, 3, 438, 906, device="cuda") * 255
+    cases += [(aa.linear_forward, xf, [196, 320]), (aa.cubic_forward, xf, [196, 320]), (aa.nearest_forward, xf, [196, 320])]
+    xc = torch.rand(3, 3, 1024, 1024, device="cuda") * 255                                              # config 2 shape
+    cases += [(aa.cubic_forward, xc, [224, 224]), (aa.linear_forward, xc, [224, 224])]
+    xo = torch.rand(2, 2, 333, 517, device="cuda") - 0.5                                                # odd sizes, signed data
+    cases += [(aa.cubic_forward, xo, [100, 129]), (aa.linear_forward, xo, [333, 100]), (aa.linear_forward, xo, [77, 517])]
+    fused_seen = set()
+    try:
+        for fn, x, size in cases:
+            _lib.set_fused(1)
+            y1 = fn(x, size)
+            fused_seen.add(_lib.last_variant())
+            _lib.set_fused(0)
+            y0 = fn(x, size)
+            assert _lib.last_variant().startswith("generic"), _lib.last_variant()
+            assert torch.equal(y1, y0), (fn.__name__, tuple(x.shape), size)
+    finally:
+        _lib.set_fused(1)
+    assert "fused_u8_nhwc_pil_v3" in fused_seen and "fused_f32_nchw" in fused_seen, fused_seen
+
+
+def test_all_fused_generations_agree(aa):
+    """The first-generation uint8 kernel stays selectable (A/B runs, shapes v3 does not take); keep it correct,
+    including the last pixel of the last image (a partially out-of-range dword must not be zeroed)."""
+    from interpolate_antialiasing_amd import _lib
+
+    torch.manual_seed(4)
+    x = torch.randint(0, 256, (7, 438, 906, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
+    try:
+        _lib.set_fused(0)
+        ref = aa.linear_forward(x, [196, 320])
+        seen = []
+        for mode in (1, 2):
+            _lib.set_fused(mode)
+            y = aa.linear_forward(x, [196, 320])
+            seen.append(_lib.last_variant())
+            assert torch.equal(y, ref), (mode, _lib.last_variant())
+    finally:
+        _lib.set_fused(1)
+    assert seen == ["fused_u8_nhwc_pil_v3", "fused_u8_nhwc_pil"], seen
+
+
+def test_nonfinite_inputs_do_not_leak(aa):
+    """fp32: a NaN/inf pixel may only reach the outputs whose window really holds it (zero-padded taps are not summed)."""
+    x = torch.rand(1, 1, 64, 128, device="cuda")
+    x[0, 0, 20, 50] = float("inf")
+    x[0, 0, 40, 90] = float("nan")
+    exp = oracle.forward("linear", x.cpu().numpy(), (23, 31))
+    got = aa.linear_forward(x, [23, 31]).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(np.isinf(got), np.isinf(exp))
+    ok = np.isfinite(exp)
+    assert np.array_equal(got[ok], exp[ok])
