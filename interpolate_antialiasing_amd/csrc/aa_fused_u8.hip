@@ -67,7 +67,7 @@ __device__ inline void load_window(__amdgpu_buffer_rsrc_t rsrc, unsigned off, un
 
 // Pillow's clip8(ss >> PRECISION_BITS) is ONE gfx950 instruction for two values: v_ashr_pk_u8_i32 D, S0, S1, sh
 // writes D[7:0] = sat_u8(S0 >> sh), D[15:8] = sat_u8(S1 >> sh) and PRESERVES the other half of D (op_sel[3]=1
-// targets D[31:16] instead) — measured on MI355X (scratch/test_pk.hip).  Written as inline asm on purpose:
+// targets D[31:16] instead) — measured on MI355X (tools/microbench/test_pk.hip).  Written as inline asm on purpose:
 // ROCm 7.2's hipcc pattern-matches `clip(a)|clip(b)<<8` to this instruction but then treats the preserved upper
 // half as zero when the 16-bit result is widened, which corrupts bytes 2-3 of a packed dword (found by the parity
 // tests).  VALU results are interlocked in hardware, so no manual wait states are needed around these.
@@ -81,7 +81,7 @@ __device__ inline unsigned pack4_clip8(int a0, int a1, int a2, int a3) {
 
 // K output rows per barrier; RB input rows of loads in flight per lane.
 // UA: byte-unaligned window loads (NV dwords straight at the window's byte offset; correct and ~1.16x faster than
-// aligned loads + v_alignbyte on gfx950 / ROCm 7.2, scratch/test_unaligned.hip) vs dword-aligned loads + alignbyte.
+// aligned loads + v_alignbyte on gfx950 / ROCm 7.2, tools/microbench/test_unaligned.hip) vs dword-aligned loads + alignbyte.
 template <int C, int TW, int K, int RB, bool UA>
 __global__ void __launch_bounds__(1024, 8)
 fused_u8_nhwc_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const char *__restrict__ tab_w,

@@ -247,10 +247,12 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     for (int c = 0; c < C; c++) A[MAXC - 1][c] = 1 << 21;
   };
   // one input row: horizontal pass from the fetched window, then scatter into the open output rows
-  auto row_step = [&](const unsigned (&d)[ND], unsigned sa, int r, const Scatter &sc) {
-    unsigned v[NV];
+  // the window of the CURRENT row, realigned; consumes the LDS reads issued one row earlier
+  auto realign = [&](const unsigned (&d)[ND], unsigned sa, unsigned (&v)[NV]) {
 #pragma unroll
     for (int k = 0; k < NV; k++) v[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sa);
+  };
+  auto row_step = [&](const unsigned (&v)[NV], int r, const Scatter &sc) {
     int acc[C];
 #pragma unroll
     for (int c = 0; c < C; c++) acc[c] = 1 << 21;
@@ -320,14 +322,24 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
       for (int i = 0; i < G; i++) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_row * (G - 2)) : "memory");
+        // Order matters for the lgkm counter (LDS and scalar loads share it and scalar loads return out of order,
+        // so every wait is lgkmcnt(0)): first consume the reads issued a whole row ago (no stall), THEN issue the
+        // next row's window reads and scatter record, which land while this row's ~45 VALU instructions run.
+        unsigned v[NV];
         if ((i & 1) == 0) {
+          realign(d0, sa0, v);
+          __builtin_amdgcn_sched_barrier(0);
           sc1 = load_scatter(r + 1);
           sa1 = fetch(a + row_bytes, (i + 1) % G, d1);
-          row_step(d0, sa0, r, sc0);
+          __builtin_amdgcn_sched_barrier(0);
+          row_step(v, r, sc0);
         } else {
+          realign(d1, sa1, v);
+          __builtin_amdgcn_sched_barrier(0);
           sc0 = load_scatter(r + 1);
           sa0 = fetch(a + row_bytes, (i + 1) % G, d0);
-          row_step(d1, sa1, r, sc1);
+          __builtin_amdgcn_sched_barrier(0);
+          row_step(v, r, sc1);
         }
         dma(a + (unsigned)G * row_bytes, i);  // the slot just consumed gets row x+G
         a += row_bytes;
@@ -345,8 +357,9 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           if ((i & 1) == 0) { sc1 = load_scatter(r + 1); sa1 = fetch(a + row_bytes, (i + 1) % G, d1, false); }
           else { sc0 = load_scatter(r + 1); sa0 = fetch(a + row_bytes, (i + 1) % G, d0, false); }
         }
-        if ((i & 1) == 0) row_step(d0, sa0, r, sc0);
-        else row_step(d1, sa1, r, sc1);
+        unsigned v[NV];
+        if ((i & 1) == 0) { realign(d0, sa0, v); row_step(v, r, sc0); }
+        else { realign(d1, sa1, v); row_step(v, r, sc1); }
         if (x + G < n_rows) dma(a + (unsigned)G * row_bytes, i);
         a += row_bytes;
         r++;

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from interpolate_antialiasing_amd import _lib, extension_interpolate as aa
 torch.manual_seed(0)
 x = torch.rand(64, 3, 1024, 1024, device='cuda') * 255

@@ -1,5 +1,5 @@
 import sys, time, json, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from interpolate_antialiasing_amd import _lib, extension_interpolate as aa
 def timeit(fn, steps=10, warm=3):
     for _ in range(warm): y = fn()
