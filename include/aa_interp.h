@@ -79,9 +79,11 @@ typedef struct aa_table_header {
   int32_t reserved[4];
 } aa_table_header;
 /* Scatter section (AA_TABLE_PIL and AA_TABLE_F32 tables), used by the fused kernels whose vertical pass runs in registers:
- * one 32-byte record per INPUT index x: { int32 first, int32 count, int32 w[6] } = the contiguous range of outputs
- * first .. first+count-1 whose window holds x and the fixed-point weight each gives it
- * (w[k] = weight[first+k][x - xmin[first+k]], zero padded).  Present only when count <= 6 everywhere. */
+ * one 32-byte record per INPUT index x (in_size + 1 records; the last is an all-zero sentinel a reader may prefetch):
+ * { int32 first, int32 count | completes << 16, int32 w[6] }.  first = the first output whose window ends at or after
+ * x; first .. first+count-1 = the outputs whose window holds x, w[k] = weight[first+k][x - xmin[first+k]] (zero
+ * padded); completes = how many outputs, starting at `first`, have x as the LAST index of their window (they can be
+ * emitted once x has been absorbed).  Present only when count <= 6 everywhere. */
 
 /* Host-side description of one axis handed to the resample calls. */
 typedef struct aa_axis {

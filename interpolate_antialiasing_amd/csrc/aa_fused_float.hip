@@ -152,7 +152,7 @@ fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, con
     const int rr = r < p.H ? r : p.H - 1;
     const int32_t *rec = sc_rec + (size_t)rr * 8;
     s.first = __builtin_amdgcn_readfirstlane(rec[0]);
-    s.cnt = __builtin_amdgcn_readfirstlane(rec[1]);
+    s.cnt = __builtin_amdgcn_readfirstlane(rec[1]) & 0xFFFF;  // (high half: outputs completing at this row)
 #pragma unroll
     for (int k = 0; k < MAXC; k++) s.w[k] = __int_as_float(__builtin_amdgcn_readfirstlane(rec[2 + k]));
     return s;

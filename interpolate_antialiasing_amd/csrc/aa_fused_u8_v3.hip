@@ -176,12 +176,6 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
     for (int c = 0; c < C; c++) A[k][c] = 1 << 21;
   int o_base = oy0;
-  int done_row;  // last input row of output o_base
-  {
-    const int m = __builtin_amdgcn_readfirstlane(ymin_h[oy0]);
-    const int s = __builtin_amdgcn_readfirstlane(ysize_h[oy0]);
-    done_row = m + (s > 1 ? s : 1) - 1;
-  }
 
   auto dma = [&](unsigned a_row, int slot) {
     const unsigned soff = a_row & ~15u;
@@ -216,17 +210,14 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     return sa;
   };
   // scatter record of an input row: first output it feeds, and its weight in that output and the next MAXC-1
-  struct Scatter { int first; int w[MAXC]; };
-  auto load_scatter = [&](int r) -> Scatter {  // one 32-byte record: {first, count, w[6]}
-    Scatter s;
-    const int rr = r < p.H ? r : p.H - 1;
-    const int32_t *rec = sc_rec + (size_t)rr * 8;
+  struct Scatter { int first; int end; int w[MAXC]; };
+  auto load_scatter = [&](int r) -> Scatter {  // one 32-byte record: {first, count | completes << 16, w[6]}
+    Scatter s;                                   // (the section has H + 1 records: r == H reads the all-zero sentinel)
+    const int32_t *rec = (const int32_t *)((const char *)sc_rec + (unsigned)r * 32u);
     s.first = __builtin_amdgcn_readfirstlane(rec[0]);
+    s.end = s.first + (__builtin_amdgcn_readfirstlane(rec[1]) >> 16);  // outputs [first, end) take their LAST row here
 #pragma unroll
-    for (int k = 0; k < MAXC; k++) {
-      const int wk = __builtin_amdgcn_readfirstlane(rec[2 + k]);
-      s.w[k] = (wk << 8) >> 8;
-    }
+    for (int k = 0; k < MAXC; k++) s.w[k] = __builtin_amdgcn_readfirstlane(rec[2 + k]);
     return s;
   };
   auto emit = [&](int oy) {  // accumulator set 0 is complete: clip, pack, merge quads, store; then slide the sets down
@@ -252,7 +243,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
     for (int k = 0; k < NV; k++) v[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sa);
   };
-  auto row_step = [&](const unsigned (&v)[NV], int r, const Scatter &sc) {
+  auto row_step = [&](const unsigned (&v)[NV], const Scatter &sc) {
     int acc[C];
 #pragma unroll
     for (int c = 0; c < C; c++) acc[c] = 1 << 21;
@@ -276,7 +267,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       for (int k = 0; k < MAXC; k++) {
         if (k >= 2 && sc.w[k] == 0) break;  // wave-uniform: most rows feed two outputs only
 #pragma unroll
-        for (int c = 0; c < C; c++) A[k][c] += h[c] * sc.w[k];
+        for (int c = 0; c < C; c++) A[k][c] += __mul24(h[c], sc.w[k]);
       }
     } else if (idx0 < 0 && idx0 > -MAXC) {
 #pragma unroll
@@ -285,18 +276,14 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
           for (int k = s; k < MAXC; k++)
 #pragma unroll
-            for (int c = 0; c < C; c++) A[k - s][c] += h[c] * sc.w[k];
+            for (int c = 0; c < C; c++) A[k - s][c] += __mul24(h[c], sc.w[k]);
         }
       }
     }
-    while (r == done_row && o_base < oy1) {
+    const int e_end = sc.end < oy1 ? sc.end : oy1;  // (outputs below o_base belong to the previous band)
+    while (o_base < e_end) {
       emit(o_base);
       o_base++;
-      if (o_base < oy1) {
-        const int m = __builtin_amdgcn_readfirstlane(ymin_h[o_base]);
-        const int s = __builtin_amdgcn_readfirstlane(ysize_h[o_base]);
-        done_row = m + (s > 1 ? s : 1) - 1;
-      }
     }
   };
 
@@ -332,14 +319,14 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           sc1 = load_scatter(r + 1);
           sa1 = fetch(a + row_bytes, (i + 1) % G, d1);
           __builtin_amdgcn_sched_barrier(0);
-          row_step(v, r, sc0);
+          row_step(v, sc0);
         } else {
           realign(d1, sa1, v);
           __builtin_amdgcn_sched_barrier(0);
           sc0 = load_scatter(r + 1);
           sa0 = fetch(a + row_bytes, (i + 1) % G, d0);
           __builtin_amdgcn_sched_barrier(0);
-          row_step(v, r, sc1);
+          row_step(v, sc1);
         }
         dma(a + (unsigned)G * row_bytes, i);  // the slot just consumed gets row x+G
         a += row_bytes;
@@ -358,8 +345,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           else { sc0 = load_scatter(r + 1); sa0 = fetch(a + row_bytes, (i + 1) % G, d0, false); }
         }
         unsigned v[NV];
-        if ((i & 1) == 0) { realign(d0, sa0, v); row_step(v, r, sc0); }
-        else { realign(d1, sa1, v); row_step(v, r, sc1); }
+        if ((i & 1) == 0) { realign(d0, sa0, v); row_step(v, sc0); }
+        else { realign(d1, sa1, v); row_step(v, sc1); }
         if (x + G < n_rows) dma(a + (unsigned)G * row_bytes, i);
         a += row_bytes;
         r++;

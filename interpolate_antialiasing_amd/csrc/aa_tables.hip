@@ -203,26 +203,30 @@ __global__ void table_transpose_kernel(const char *fwd, int32_t *tmin, int32_t *
 __global__ void table_scatter_kernel(const char *fwd, int32_t *rec_all, int32_t *scatter_max, int in_size, int out_size,
                                      int ksize) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= in_size) return;
+  if (x > in_size) return;  // record in_size is a sentinel (feeds nothing, completes nothing): readers may prefetch it
   const int32_t *xmin = (const int32_t *)(fwd + aa_table_xmin_off());
   const int32_t *xsize = (const int32_t *)(fwd + aa_table_xsize_off(out_size));
   const int32_t *w = (const int32_t *)(fwd + aa_table_w_off(out_size));
   int32_t *rec = rec_all + (size_t)x * 8;
-  int lo = 0, hi = out_size;
-  while (lo < hi) {  // first o with xmin[o] + max(xsize[o],1) > x
-    const int mid = (lo + hi) >> 1;
-    const int xs = xsize[mid] > 1 ? xsize[mid] : 1;
-    if (xmin[mid] + xs > x) hi = mid; else lo = mid + 1;
-  }
-  const int first = lo;
-  lo = first; hi = out_size;
+  auto first_ending_after = [&](int row) {  // first o whose last input row, xmin[o] + max(xsize[o],1) - 1, is >= row
+    int lo = 0, hi = out_size;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const int xs = xsize[mid] > 1 ? xsize[mid] : 1;
+      if (xmin[mid] + xs > row) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+  };
+  const int first = first_ending_after(x);
+  const int completes = first_ending_after(x + 1) - first;  // outputs [first, first+completes) end exactly at row x
+  int lo = first, hi = out_size;
   while (lo < hi) {  // first o with xmin[o] > x
     const int mid = (lo + hi) >> 1;
     if (xmin[mid] > x) hi = mid; else lo = mid + 1;
   }
-  const int cnt = lo - first > 0 ? lo - first : 0;
-  rec[0] = cnt > 0 ? first : 0;
-  rec[1] = cnt;
+  const int cnt = (x < in_size && lo - first > 0) ? lo - first : 0;
+  rec[0] = first;
+  rec[1] = cnt | (completes << 16);
   for (int k = 0; k < 6; k++) {
     const int o = first + k;
     rec[2 + k] = (k < cnt) ? w[(size_t)o * ksize + (x - xmin[o])] : 0;
@@ -259,7 +263,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
     hipLaunchKernelGGL(table_build_f32, dim3(blocks), dim3(threads), 0, stream, filter, (int)in_size, (int)out_size, ksize,
                        (float)scale, t);
     if (h.scatter_off) {  // float weights travel through the 32-bit record fields bit for bit
-      const int b2 = (int)((in_size + threads - 1) / threads);
+      const int b2 = (int)((in_size + 1 + threads - 1) / threads);
       hipLaunchKernelGGL(table_scatter_kernel, dim3(b2), dim3(threads), 0, stream, (const char *)t,
                          (int32_t *)(t + h.scatter_off), &((aa_table_header *)t)->scatter_max, (int)in_size, (int)out_size,
                          ksize);
@@ -273,7 +277,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
     if (h.scatter_off) {
       // scatter (adjoint-form) section for the fused kernels' in-register vertical pass: for every INPUT index the
       // outputs it feeds and their fixed-point weights
-      const int b2 = (int)((in_size + threads - 1) / threads);
+      const int b2 = (int)((in_size + 1 + threads - 1) / threads);
       hipLaunchKernelGGL(table_scatter_kernel, dim3(b2), dim3(threads), 0, stream, (const char *)t,
                          (int32_t *)(t + h.scatter_off), &((aa_table_header *)t)->scatter_max, (int)in_size, (int)out_size,
                          ksize);

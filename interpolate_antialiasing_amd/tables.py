@@ -72,7 +72,7 @@ class WeightTable:
 
     # ---- inspection (tests) ----------------------------------------------------------------------------
     def unpack_scatter(self):
-        """-> (tmin int32[in], tsize int32[in], tw int32[in, scatter_ksize]) of an AA_TABLE_PIL table (CPU numpy)."""
+        """-> (first int32[in], count int32[in], w int32[in, scatter_ksize], completes int32[in]) (CPU numpy)."""
         import numpy as np
 
         if not self.scatter_off:
@@ -80,7 +80,7 @@ class WeightTable:
         raw = self.buf.detach().cpu().numpy()
         n, off = self.in_size, self.scatter_off
         rec = raw[off:off + 32 * n].view(np.int32).reshape(n, 8).copy()
-        return rec[:, 0], rec[:, 1], rec[:, 2:]
+        return rec[:, 0], rec[:, 1] & 0xFFFF, rec[:, 2:], rec[:, 1] >> 16
 
     def unpack(self):
         """-> (xmin int32[out], xsize int32[out], w [out,ksize]) as CPU numpy arrays."""

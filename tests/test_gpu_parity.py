@@ -65,6 +65,19 @@ def test_device_pil_tables_bit_exact(aa, filt):
         dxmin, dxsize, dw = t.unpack()
         assert t.ksize == k
         assert np.array_equal(dxmin, xmin) and np.array_equal(dxsize, xsize) and np.array_equal(dw, kk), (filt, n_in, n_out)
+        sc = t.unpack_scatter()
+        if sc is not None and t.scatter_max <= t.scatter_ksize:  # the adjoint-form records the fused kernels read
+            first, count, w, completes = sc
+            last = xmin + np.maximum(xsize, 1) - 1  # last input index of every output's window
+            dense = np.zeros((n_in, n_out), np.int64)
+            for o in range(n_out):
+                dense[xmin[o]:xmin[o] + xsize[o], o] = kk[o, :xsize[o]]
+            for x in range(n_in):
+                fed = np.nonzero((xmin <= x) & (last >= x))[0]
+                assert count[x] == len(fed) and (len(fed) == 0 or first[x] == fed[0]), (filt, n_in, n_out, x)
+                assert np.array_equal(w[x, :count[x]], dense[x, first[x]:first[x] + count[x]]) and not w[x, count[x]:].any()
+                assert completes[x] == np.count_nonzero(last == x) and (completes[x] == 0 or last[first[x]] == x)
+            assert completes.sum() == n_out
 
 
 def test_align_corners_tables(aa):
