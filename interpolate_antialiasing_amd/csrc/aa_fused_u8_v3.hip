@@ -27,6 +27,15 @@
 
 #include "aa_common.h"
 
+#ifndef AA_V3_ABL
+#define AA_V3_ABL 0  // developer ablations (wrong results!): 1 no stores, 2 no DMA waits, 4 no DMA at all,
+                     // 5 no horizontal MACs, 6 DMA only (no LDS reads, no arithmetic, no stores)
+#endif
+
+#ifndef AA_V3_AUX
+#define AA_V3_AUX 0  // cache-policy bits of the staging DMA (developer knob)
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -178,12 +187,13 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   int o_base = oy0;
 
   auto dma = [&](unsigned a_row, int slot) {
-    const unsigned soff = a_row & ~15u;
+    if (AA_V3_ABL == 4) return;
+    const unsigned soff = AA_V3_ABL == 7 ? (a_row & 0x3F0u) : (a_row & ~15u);  // 7: every DMA hits the same 1.6 KB
     const int dst = lds_base + slot * p.seg_bytes;
-    if (dma_lane0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, soff, 0, 0);
+    if (dma_lane0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, soff, 0, AA_V3_AUX);
     if constexpr (TWO_DMA) {
       if (dma_lane1)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst + 1024), 16, voff + 1024, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst + 1024), 16, voff + 1024, soff, 0, AA_V3_AUX);
     }
   };
   // per-slot loop invariants of the window reads (PERIODIC only): dword-aligned LDS address and 16-byte phase
@@ -197,6 +207,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   }
   auto fetch = [&](unsigned a_row, int slot, unsigned (&d)[ND], bool tables = true) -> unsigned {
     unsigned sa, ra;
+    if (AA_V3_ABL == 6) return 0;
     if (PERIODIC && tables) {  // `slot` must be a compile-time constant here (register arrays)
       sa = lane_lds + slot_ph[slot];  // only its low two bits are used (v_alignbyte)
       ra = slot_ra[slot];
@@ -210,12 +221,12 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     return sa;
   };
   // scatter record of an input row: first output it feeds, and its weight in that output and the next MAXC-1
-  struct Scatter { int first; int end; int w[MAXC]; };
+  struct Scatter { int first; int cc; int w[MAXC]; };  // raw record words (nothing depends on them until they are used)
   auto load_scatter = [&](int r) -> Scatter {  // one 32-byte record: {first, count | completes << 16, w[6]}
     Scatter s;                                   // (the section has H + 1 records: r == H reads the all-zero sentinel)
     const int32_t *rec = (const int32_t *)((const char *)sc_rec + (unsigned)r * 32u);
     s.first = __builtin_amdgcn_readfirstlane(rec[0]);
-    s.end = s.first + (__builtin_amdgcn_readfirstlane(rec[1]) >> 16);  // outputs [first, end) take their LAST row here
+    s.cc = __builtin_amdgcn_readfirstlane(rec[1]);  // count | completes << 16
 #pragma unroll
     for (int k = 0; k < MAXC; k++) s.w[k] = __builtin_amdgcn_readfirstlane(rec[2 + k]);
     return s;
@@ -225,7 +236,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       const unsigned t = pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][2]);
       const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xF, 0xF, false);
       const unsigned dw = __builtin_amdgcn_perm(nb, t, perm_sel);
-      if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+      if (store_lane && (AA_V3_ABL != 1 || dw == 0x12345678u))
+        __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
     } else {
       const unsigned dw = pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][C - 1]);
       if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
@@ -244,11 +256,12 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     for (int k = 0; k < NV; k++) v[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sa);
   };
   auto row_step = [&](const unsigned (&v)[NV], const Scatter &sc) {
+    if (AA_V3_ABL == 6) return;
     int acc[C];
 #pragma unroll
-    for (int c = 0; c < C; c++) acc[c] = 1 << 21;
+    for (int c = 0; c < C; c++) acc[c] = AA_V3_ABL == 5 ? (int)v[c] : 1 << 21;
 #pragma unroll
-    for (int j = 0; j < TW; j++) {
+    for (int j = 0; j < (AA_V3_ABL == 5 ? 0 : TW); j++) {
 #pragma unroll
       for (int c = 0; c < C; c++) {
         const int bi = j * C + c;
@@ -280,7 +293,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
         }
       }
     }
-    const int e_end = sc.end < oy1 ? sc.end : oy1;  // (outputs below o_base belong to the previous band)
+    const int sc_end = sc.first + (sc.cc >> 16);     // outputs [first, sc_end) take their LAST row here
+    const int e_end = sc_end < oy1 ? sc_end : oy1;  // (outputs below o_base belong to the previous band)
     while (o_base < e_end) {
       emit(o_base);
       o_base++;
@@ -308,7 +322,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     if (x0 + 2 * G <= n_rows) {  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
 #pragma unroll
       for (int i = 0; i < G; i++) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_row * (G - 2)) : "memory");
+        if (AA_V3_ABL != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_row * (G - 2)) : "memory");
         // Order matters for the lgkm counter (LDS and scalar loads share it and scalar loads return out of order,
         // so every wait is lgkmcnt(0)): first consume the reads issued a whole row ago (no stall), THEN issue the
         // next row's window reads and scatter record, which land while this row's ~45 VALU instructions run.
@@ -437,6 +451,9 @@ int launch(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, i
 
 template <int C>
 int dispatch_tw(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
+#ifdef AA_V3_HEADLINE_ONLY  // developer builds: one window width, so the file compiles in seconds
+  return tw == 6 ? launch<C, 6>(maxc, p, q, lds, grid) : 0;
+#endif
   if (tw <= 2) return launch<C, 2>(maxc, p, q, lds, grid);
   if (tw <= 4) return launch<C, 4>(maxc, p, q, lds, grid);
   if (tw <= 6) return launch<C, 6>(maxc, p, q, lds, grid);
