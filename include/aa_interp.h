@@ -163,8 +163,7 @@ int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *wo
 size_t aa_workspace_bytes_bwd(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, int64_t oH, int64_t oW);
 
 /* Kernel selection, process-wide; returns the previous setting.  1 (default): fused single-launch kernels, newest
- * design first; 2: first-generation fused kernels only, 3: without the producer-wave kernel (A/B measurements);
- * 0: none.
+ * design first; 2: first-generation fused kernels only (A/B measurements); 0: none.
  * With 0 every call takes the generic two-launch path — used by tests to cross-check the fused kernels against an
  * independent implementation at sizes the CPU oracle cannot reach, and by bench.py for A/B numbers. */
 int aa_set_fused(int enabled);

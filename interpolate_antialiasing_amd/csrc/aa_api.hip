@@ -230,8 +230,7 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
   const char *variant = "none";
   rc = 0;
   if (g_fused_enabled) {
-    if (g_fused_enabled == 1) rc = aa_try_fused_u8_nhwc_v4(p, &variant);
-    if (rc == 0 && (g_fused_enabled == 1 || g_fused_enabled == 3)) rc = aa_try_fused_u8_nhwc_v3(p, &variant);
+    if (g_fused_enabled == 1) rc = aa_try_fused_u8_nhwc_v3(p, &variant);
     if (rc == 0) rc = aa_try_fused_u8_nhwc(p, &variant);
     if (rc == 0) rc = aa_try_fused_float_nchw(p, &variant);
   }
@@ -295,9 +294,8 @@ int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *wo
 
 int aa_set_fused(int enabled) {
   const int prev = g_fused_enabled;
-  // 0 generic two-pass, 1 auto (newest fused design first), 2 first-generation fused kernels only,
-  // 3 skip the producer-wave kernel (wave-autonomous v3 first)
-  g_fused_enabled = (enabled < 0 || enabled > 3) ? 1 : enabled;
+  // 0 generic two-pass, 1 auto (newest fused design first), 2 first-generation fused kernels only
+  g_fused_enabled = (enabled < 0 || enabled > 2) ? 1 : enabled;
   return prev;
 }
 

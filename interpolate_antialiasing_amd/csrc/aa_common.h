@@ -74,7 +74,6 @@ size_t aa_generic_workspace_bytes(int dtype, int kind_w, int64_t N, int64_t C, i
 int aa_try_fused_u8_nhwc(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw(const AAProblem &p, const char **variant);
 int aa_try_fused_u8_nhwc_v3(const AAProblem &p, const char **variant);  // LDS-DMA staged, wave-autonomous, V pass in registers
-int aa_try_fused_u8_nhwc_v4(const AAProblem &p, const char **variant);  // v3's arithmetic waves fed by a producer (DMA) wave
 bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 // CU count of the current device (cached); 256 on MI355X
