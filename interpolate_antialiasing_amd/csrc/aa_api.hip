@@ -233,6 +233,7 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
     if (g_fused_enabled == 1) rc = aa_try_fused_u8_nhwc_v3(p, &variant);
     if (rc == 0) rc = aa_try_fused_u8_nhwc(p, &variant);
     if (rc == 0) rc = aa_try_fused_float_nchw(p, &variant);
+    if (rc == 0) rc = aa_try_fused_float_nchw_up(p, &variant);
   }
   if (rc < 0) return rc;
   if (rc == 1) {

@@ -342,6 +342,13 @@ def test_fused_kernels_match_generic_at_full_size(aa):
     cases += [(aa.cubic_forward, xc, [224, 224]), (aa.linear_forward, xc, [224, 224])]
     xo = torch.rand(2, 2, 333, 517, device="cuda") - 0.5                                                # odd sizes, signed data
     cases += [(aa.cubic_forward, xo, [100, 129]), (aa.linear_forward, xo, [333, 100]), (aa.linear_forward, xo, [77, 517])]
+    xu = torch.rand(2, 3, 438, 906, device="cuda") * 255                                                # test.py's up-scales
+    cases += [(aa.linear_forward, xu, [1200, 1200]), (aa.cubic_forward, xu, [1200, 1200]), (aa.linear_forward, xo, [400, 300]),
+              (aa.nearest_forward, xo, [500, 600]), (aa.cubic_forward, xo, [333, 900])]
+    go = torch.randn(8, 3, 196, 320, device="cuda")                                                     # config 5, batched
+    bwd = lambda fn, ishape: (lambda g, size: fn(g, size, ishape))
+    cases += [(bwd(aa.linear_backward, [8, 3, 438, 906]), go, [196, 320]), (bwd(aa.cubic_backward, [8, 3, 438, 906]), go, [196, 320]),
+              (bwd(aa.linear_backward, [8, 3, 196, 906]), go, [196, 320]), (bwd(aa.linear_backward, [8, 3, 500, 320]), go, [196, 320])]
     fused_seen = set()
     try:
         for fn, x, size in cases:
@@ -351,10 +358,10 @@ def test_fused_kernels_match_generic_at_full_size(aa):
             _lib.set_fused(0)
             y0 = fn(x, size)
             assert _lib.last_variant().startswith("generic"), _lib.last_variant()
-            assert torch.equal(y1, y0), (fn.__name__, tuple(x.shape), size)
+            assert torch.equal(y1, y0), (getattr(fn, "__name__", "backward"), tuple(x.shape), size)
     finally:
         _lib.set_fused(1)
-    assert "fused_u8_nhwc_pil_v3" in fused_seen and "fused_f32_nchw" in fused_seen, fused_seen
+    assert {"fused_u8_nhwc_pil_v3", "fused_f32_nchw", "fused_f32_nchw_up"} <= fused_seen, fused_seen
 
 
 def test_all_fused_generations_agree(aa):
@@ -385,6 +392,12 @@ def test_nonfinite_inputs_do_not_leak(aa):
     x[0, 0, 40, 90] = float("nan")
     exp = oracle.forward("linear", x.cpu().numpy(), (23, 31))
     got = aa.linear_forward(x, [23, 31]).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(np.isinf(got), np.isinf(exp))
+    ok = np.isfinite(exp)
+    assert np.array_equal(got[ok], exp[ok])
+    # growing heights take the gather-form kernel: same rule
+    exp = oracle.forward("linear", x.cpu().numpy(), (100, 200))
+    got = aa.linear_forward(x, [100, 200]).cpu().numpy()
     assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(np.isinf(got), np.isinf(exp))
     ok = np.isfinite(exp)
     assert np.array_equal(got[ok], exp[ok])
