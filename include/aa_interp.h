@@ -48,7 +48,10 @@ enum aa_status {
 enum aa_filter { AA_FILTER_LINEAR = 0, AA_FILTER_CUBIC = 1, AA_FILTER_BOX = 2 };
 
 /* Element type of the image tensors. */
-enum aa_dtype { AA_U8 = 0, AA_F32 = 1, AA_F64 = 2 };
+enum aa_dtype { AA_U8 = 0, AA_F32 = 1, AA_F64 = 2, AA_F16 = 3, AA_BF16 = 4 };
+/* AA_F16 / AA_BF16 (the reference dispatches float and double only): AA_TABLE_F32 tables, fp32
+ * arithmetic in the reference's order, fp32 intermediate between the passes, ONE round-to-nearest-even at the store —
+ * i.e. exactly  half(reference_fp32(float(x))). */
 
 enum aa_layout { AA_NCHW = 0, AA_NHWC = 1 };
 
@@ -161,6 +164,14 @@ int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *wo
                            int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h,
                            const aa_axis *ax_w, aa_stream_t stream);
 size_t aa_workspace_bytes_bwd(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, int64_t oH, int64_t oW);
+
+/* One separable pass along one axis of a dense array viewed as [outer][in_size][inner] -> [outer][out_size][inner]
+ * (the body the reference instantiates per dimension, `_ti_separable_upsample_generic_Nd_kernel_impl_single_dim`
+ * s2.2/aa_interpolation_impl.h:536-625, "NCHW, NCL or NCKHW" :545).  The N-d front-ends (1-D NCL, 3-D NCDHW) are this
+ * call once per resampled axis, last axis first like the reference (:658); no workspace.  dtype/table-kind pairs as
+ * for aa_resample_fwd except u8 with AA_TABLE_F32 (the harness mode needs a float intermediate). */
+int aa_resample_axis_fwd(const void *in_dev, void *out_dev, int dtype, int64_t outer, int64_t in_size, int64_t inner,
+                         const aa_axis *ax, aa_stream_t stream);
 
 /* Kernel selection, process-wide; returns the previous setting.  1 (default): fused single-launch kernels, newest
  * design first; 2: first-generation fused kernels only (A/B measurements); 0: none.

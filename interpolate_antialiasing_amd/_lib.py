@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "aa_interp.h")
 # enums (include/aa_interp.h)
 AA_OK = 0
 FILTER_LINEAR, FILTER_CUBIC, FILTER_BOX = 0, 1, 2
-U8, F32, F64 = 0, 1, 2
+U8, F32, F64, F16, BF16 = 0, 1, 2, 3, 4
 NCHW, NHWC = 0, 1
 TABLE_PIL, TABLE_F32, TABLE_F64 = 0, 1, 2
 ERR_BAD_DTYPE = -2
@@ -25,7 +25,8 @@ ERR_BAD_DTYPE = -2
 EXPORTS = (
     "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build_bytes", "aa_table_build",
     "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_workspace_bytes", "aa_resample_fwd",
-    "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_set_fused", "aa_last_variant",
+    "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_resample_axis_fwd", "aa_set_fused",
+    "aa_last_variant",
 )
 
 
@@ -96,6 +97,8 @@ def load() -> ctypes.CDLL:
     L.aa_resample_bwd_atomic.restype = i32
     L.aa_workspace_bytes_bwd.argtypes = [i32, i32, i64, i64, i64, i64, i64, i64]
     L.aa_workspace_bytes_bwd.restype = sz
+    L.aa_resample_axis_fwd.argtypes = [vp, vp, i32, i64, i64, i64, ax, vp]
+    L.aa_resample_axis_fwd.restype = i32
     L.aa_last_variant.restype = ctypes.c_char_p
     L.aa_set_fused.argtypes = [i32]
     L.aa_set_fused.restype = i32

@@ -64,6 +64,7 @@ int check_dtype_kind(int dtype, int kh, int kw) {
   if (dtype == AA_F32 && kh == AA_TABLE_F32) return AA_OK;
   if (dtype == AA_F64 && kh == AA_TABLE_F64) return AA_OK;
   if (dtype == AA_U8 && (kh == AA_TABLE_PIL || kh == AA_TABLE_F32)) return AA_OK;
+  if ((dtype == AA_F16 || dtype == AA_BF16) && kh == AA_TABLE_F32) return AA_OK;
   return AA_ERR_BAD_DTYPE;
 }
 
@@ -198,6 +199,7 @@ size_t aa_workspace_bytes(int dtype, int layout, int64_t N, int64_t C, int64_t H
   if (g_fused_enabled) {
     if (aa_fused_u8_nhwc_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
     if (aa_fused_float_nchw_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
+    if (aa_fused_float_nchw_up_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
   }
   return aa_generic_workspace_bytes(dtype, ax_w->kind, N, C, H, oW);
 }
@@ -205,7 +207,7 @@ size_t aa_workspace_bytes(int dtype, int layout, int64_t N, int64_t C, int64_t H
 int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
                     int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
                     aa_stream_t stream) {
-  if (dtype != AA_U8 && dtype != AA_F32 && dtype != AA_F64) return AA_ERR_BAD_DTYPE;
+  if (dtype < AA_U8 || dtype > AA_BF16) return AA_ERR_BAD_DTYPE;
   if (layout != AA_NCHW && layout != AA_NHWC) return AA_ERR_BAD_LAYOUT;
   if (N < 0 || C <= 0 || H <= 0 || W <= 0) return AA_ERR_BAD_SHAPE;
   int rc = check_axis(ax_h, H);
@@ -291,6 +293,21 @@ int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *wo
   p.ah = *ax_h; p.aw = *ax_w;
   p.stream = (hipStream_t)stream;
   return aa_launch_bwd_atomic(p);
+}
+
+int aa_resample_axis_fwd(const void *in_dev, void *out_dev, int dtype, int64_t outer, int64_t in_size, int64_t inner,
+                         const aa_axis *ax, aa_stream_t stream) {
+  if (dtype < AA_U8 || dtype > AA_BF16) return AA_ERR_BAD_DTYPE;
+  if (outer < 0 || in_size <= 0 || inner <= 0) return AA_ERR_BAD_SHAPE;
+  int rc = check_axis(ax, in_size);
+  if (rc != AA_OK) return rc;
+  if (dtype == AA_U8 && ax->kind != AA_TABLE_PIL) return AA_ERR_BAD_DTYPE;
+  rc = check_dtype_kind(dtype, ax->kind, ax->kind);
+  if (rc != AA_OK) return rc;
+  if (outer == 0) return AA_OK;
+  if (!in_dev || !out_dev) return AA_ERR_NULL;
+  g_last_variant = "generic_axis";
+  return aa_launch_axis_fwd(in_dev, out_dev, dtype, outer, in_size, inner, *ax, (hipStream_t)stream);
 }
 
 int aa_set_fused(int enabled) {

@@ -69,6 +69,8 @@ struct AAProblem {
 
 // generic two-launch separable path (always available); returns variant name through *variant
 int aa_launch_generic_fwd(const AAProblem &p, const char **variant);
+int aa_launch_axis_fwd(const void *in, void *out, int dtype, int64_t outer, int64_t in_size, int64_t inner, const aa_axis &ax,
+                       hipStream_t stream);
 size_t aa_generic_workspace_bytes(int dtype, int kind_w, int64_t N, int64_t C, int64_t H, int64_t oW);
 // fused single-launch paths; return 1 when they took the problem, 0 when not applicable, <0 on error
 int aa_try_fused_u8_nhwc(const AAProblem &p, const char **variant);
@@ -76,6 +78,7 @@ int aa_try_fused_float_nchw(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw_up(const AAProblem &p, const char **variant);  // H <= oH: adjoint (gather form), up-scaling
 int aa_try_fused_u8_nhwc_v3(const AAProblem &p, const char **variant);  // LDS-DMA staged, wave-autonomous, V pass in registers
 bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
+bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 // CU count of the current device (cached); 256 on MI355X
 int aa_device_cu_count();

@@ -280,16 +280,29 @@ int launch_kr(int kr, const FusedF32UpParams &p, const AAProblem &q, size_t lds)
 
 }  // namespace
 
+bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah,
+                                       const aa_axis *aw) {
+  (void)C;
+  if (dtype != AA_F32 || layout != AA_NCHW) return false;
+  if (!ah || !aw || ah->kind != AA_TABLE_F32 || aw->kind != AA_TABLE_F32) return false;
+  if (H > ah->out_size) return false;  // shrinking heights: aa_fused_float.hip
+  const int taps_h = ah->max_taps > 0 ? ah->max_taps : ah->ksize;
+  const int taps_w = aw->max_taps > 0 ? aw->max_taps : aw->ksize;
+  if (taps_h > 8 || taps_w > 8) return false;
+  const int tw = taps_w <= 2 ? 2 : (taps_w <= 4 ? 4 : 8);
+  if (W < tw) return false;
+  if ((uint64_t)H * W * 4 > 0xFFFFFFF0ull || (uint64_t)ah->out_size * aw->out_size * 4 > 0xFFFFFFF0ull) return false;
+  const double scale_w = (double)W / (double)aw->out_size;
+  const int span_px = (int)floor(63.0 * (scale_w > 0 ? scale_w : 0)) + 1 + tw;
+  if ((span_px * 4 + 15 + 15) / 16 > 64) return false;  // one DMA instruction per staged row
+  return true;
+}
+
 int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
-  if (q.dtype != AA_F32 || q.layout != AA_NCHW) return 0;
-  if (q.ah.kind != AA_TABLE_F32 || q.aw.kind != AA_TABLE_F32) return 0;
-  if (q.H > q.oH) return 0;  // shrinking heights: aa_fused_float.hip
+  if (!aa_fused_float_nchw_up_applicable(q.dtype, q.layout, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   const int taps_w = q.aw.max_taps > 0 ? q.aw.max_taps : q.aw.ksize;
-  if (taps_h > 8 || taps_w > 8) return 0;
   const int tw = taps_w <= 2 ? 2 : (taps_w <= 4 ? 4 : 8);
-  if (q.W < tw) return 0;
-  if ((uint64_t)q.H * q.W * 4 > 0xFFFFFFF0ull || (uint64_t)q.oH * q.oW * 4 > 0xFFFFFFF0ull) return 0;
   if (((uintptr_t)q.out & 3) != 0 || ((uintptr_t)q.in & 3) != 0) return 0;
 
   FusedF32UpParams p;
@@ -307,7 +320,6 @@ int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   const double scale_w = (double)q.W / (double)q.oW;
   const int span_px = (int)floor(63.0 * (scale_w > 0 ? scale_w : 0)) + 1 + tw;
   p.nseg = (span_px * 4 + 15 + 15) / 16;
-  if (p.nseg > 64) return 0;  // one DMA instruction per staged row
   p.seg_bytes = p.nseg * 16;
   p.ybands = 1;
   const size_t lds = (size_t)8 * p.seg_bytes;

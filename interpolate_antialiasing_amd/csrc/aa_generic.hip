@@ -20,10 +20,18 @@
 namespace {
 
 // ---- per-pipeline arithmetic -----------------------------------------------------------------------------
+// 16-bit floats: storage types only, all arithmetic is fp32 (PipeF32)
+struct f16_t { _Float16 v; };
+struct bf16_t { uint16_t v; };
+__device__ inline float to_f32(float x) { return x; }
+__device__ inline float to_f32(uint8_t x) { return (float)x; }
+__device__ inline float to_f32(f16_t x) { return (float)x.v; }
+__device__ inline float to_f32(bf16_t x) { return __uint_as_float((unsigned)x.v << 16); }
+
 struct PipeF32 {
   using W = float; using Acc = float;
-  template <typename T> static __device__ inline Acc first(T x, W w) { return (float)x * w; }
-  template <typename T> static __device__ inline Acc next(Acc a, T x, W w) { return a + (float)x * w; }
+  template <typename T> static __device__ inline Acc first(T x, W w) { return to_f32(x) * w; }
+  template <typename T> static __device__ inline Acc next(Acc a, T x, W w) { return a + to_f32(x) * w; }
 };
 struct PipeF64 {
   using W = double; using Acc = double;
@@ -39,6 +47,18 @@ struct PipePIL {  // Pillow 8bpc: ss0 = 1 << (PRECISION_BITS-1); ss0 += pixel * 
 template <typename TOut, typename Acc>
 struct Store;
 template <> struct Store<float, float> { static __device__ inline float cvt(float a, int) { return a; } };
+template <> struct Store<f16_t, float> {  // round to nearest even
+  static __device__ inline f16_t cvt(float a, int) { f16_t r; r.v = (_Float16)a; return r; }
+};
+template <> struct Store<bf16_t, float> {  // round to nearest even, NaN stays NaN
+  static __device__ inline bf16_t cvt(float a, int) {
+    const unsigned u = __float_as_uint(a);
+    bf16_t r;
+    if ((u & 0x7fffffffu) > 0x7f800000u) r.v = (uint16_t)((u >> 16) | 0x0040u);
+    else r.v = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    return r;
+  }
+};
 template <> struct Store<double, double> { static __device__ inline double cvt(double a, int) { return a; } };
 template <> struct Store<uint8_t, int32_t> {  // clip8(ss >> PRECISION_BITS)
   static __device__ inline uint8_t cvt(int32_t a, int) {
@@ -133,7 +153,7 @@ int run_two_pass(const AAProblem &p) {
 size_t aa_generic_workspace_bytes(int dtype, int kind_w, int64_t N, int64_t C, int64_t H, int64_t oW) {
   size_t elem;
   if (dtype == AA_F64) elem = 8;
-  else if (dtype == AA_F32) elem = 4;
+  else if (dtype == AA_F32 || dtype == AA_F16 || dtype == AA_BF16) elem = 4;  // 16-bit floats: fp32 intermediate
   else elem = (kind_w == AA_TABLE_PIL) ? 1 : 4;  // u8: Pillow keeps a uint8 intermediate, the harness an fp32 one
   return aa_align16((size_t)N * C * H * oW * elem);
 }
@@ -155,5 +175,34 @@ int aa_launch_generic_fwd(const AAProblem &p, const char **variant) {
     *variant = "generic_2pass_u8_harness";
     return run_two_pass<PipeF32, uint8_t, float, uint8_t>(p);
   }
+  if (p.dtype == AA_F16 && p.aw.kind == AA_TABLE_F32 && p.ah.kind == AA_TABLE_F32) {
+    *variant = "generic_2pass_f16";
+    return run_two_pass<PipeF32, f16_t, float, f16_t>(p);
+  }
+  if (p.dtype == AA_BF16 && p.aw.kind == AA_TABLE_F32 && p.ah.kind == AA_TABLE_F32) {
+    *variant = "generic_2pass_bf16";
+    return run_two_pass<PipeF32, bf16_t, float, bf16_t>(p);
+  }
+  return AA_ERR_BAD_DTYPE;
+}
+
+// one pass along one axis of [outer][in_size][inner]
+template <typename Pipe, typename T>
+static int run_axis(const void *in, void *out, int64_t outer, int64_t in_size, int64_t inner, const aa_axis &ax, hipStream_t stream) {
+  const int64_t total = outer * ax.out_size * inner;
+  if (total == 0) return AA_OK;
+  hipLaunchKernelGGL((vpass_generic<Pipe, T, T>), dim3(grid_for(total)), dim3(256), 0, stream, (const T *)in, (T *)out,
+                     (const char *)ax.table_dev, total, (int)in_size, (int)ax.out_size, inner, ax.ksize);
+  AA_HIP_CHECK_LAUNCH();
+  return AA_OK;
+}
+
+int aa_launch_axis_fwd(const void *in, void *out, int dtype, int64_t outer, int64_t in_size, int64_t inner, const aa_axis &ax,
+                       hipStream_t stream) {
+  if (dtype == AA_F32 && ax.kind == AA_TABLE_F32) return run_axis<PipeF32, float>(in, out, outer, in_size, inner, ax, stream);
+  if (dtype == AA_F64 && ax.kind == AA_TABLE_F64) return run_axis<PipeF64, double>(in, out, outer, in_size, inner, ax, stream);
+  if (dtype == AA_U8 && ax.kind == AA_TABLE_PIL) return run_axis<PipePIL, uint8_t>(in, out, outer, in_size, inner, ax, stream);
+  if (dtype == AA_F16 && ax.kind == AA_TABLE_F32) return run_axis<PipeF32, f16_t>(in, out, outer, in_size, inner, ax, stream);
+  if (dtype == AA_BF16 && ax.kind == AA_TABLE_F32) return run_axis<PipeF32, bf16_t>(in, out, outer, in_size, inner, ax, stream);
   return AA_ERR_BAD_DTYPE;
 }

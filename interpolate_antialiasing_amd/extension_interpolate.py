@@ -32,11 +32,13 @@ import torch
 from . import _lib, tables
 
 __all__ = ["linear_forward", "nearest_forward", "cubic_forward", "linear_backward", "cubic_backward",
-           "nearest_backward", "forward", "set_uint8_mode", "get_uint8_mode", "last_variant"]
+           "nearest_backward", "forward", "linear_forward_nd", "cubic_forward_nd", "nearest_forward_nd", "set_uint8_mode",
+           "get_uint8_mode", "last_variant"]
 
 _uint8_mode = "pil"
 
-_DTYPE_IDS = {torch.uint8: _lib.U8, torch.float32: _lib.F32, torch.float64: _lib.F64}
+_DTYPE_IDS = {torch.uint8: _lib.U8, torch.float32: _lib.F32, torch.float64: _lib.F64, torch.float16: _lib.F16,
+              torch.bfloat16: _lib.BF16}
 _DTYPE_NAMES = {torch.float16: "Half", torch.bfloat16: "BFloat16", torch.int8: "Char", torch.int16: "Short",
                 torch.int32: "Int", torch.int64: "Long", torch.bool: "Bool", torch.uint8: "Byte"}
 
@@ -82,7 +84,7 @@ def _memory_format(x: torch.Tensor):
 
 
 def _table_kind(dtype: torch.dtype, uint8_mode: Optional[str]) -> int:
-    if dtype == torch.float32:
+    if dtype in (torch.float32, torch.float16, torch.bfloat16):  # 16-bit floats compute in fp32
         return _lib.TABLE_F32
     if dtype == torch.float64:
         return _lib.TABLE_F64
@@ -179,6 +181,70 @@ def _backward(filter_id: int, name: str, grad_output: torch.Tensor, output_size:
                                    n, c, h, w, ctypes.byref(trh), ctypes.byref(trw), s)
     _lib.check(rc, name)
     return gi
+
+
+def _forward_nd(filter_id: int, name: str, input: torch.Tensor, output_size: Sequence[int], align_corners: bool) -> torch.Tensor:
+    """1-D (NCL) and 3-D (NCDHW) front-ends: the reference's separable driver is N-d generic
+    (s2.2/aa_interpolation_impl.h:536-683, "NCHW, NCL or NCKHW" :545) although only the 2-D callables are bound.
+    One aa_resample_axis_fwd per resampled axis, LAST axis first like the reference (:658), contiguous intermediates."""
+    if not isinstance(input, torch.Tensor):
+        raise TypeError(f"{name}(): argument 'input' must be Tensor")
+    nd = input.dim() - 2
+    if nd not in (1, 2, 3):
+        raise RuntimeError(f"It is expected input_size equals to 3, 4 or 5, but got size {input.dim()}")
+    if len(output_size) != nd:
+        raise RuntimeError(f"It is expected output_size equals to {nd}, but got size {len(output_size)}")
+    if nd == 2:
+        return _forward(filter_id, name, input, output_size, align_corners)
+    sizes = [int(v) for v in input.shape[2:]]
+    osizes = [int(v) for v in output_size]
+    if not all(v > 0 for v in sizes + osizes):
+        raise RuntimeError(f"Input and output sizes should be greater than 0, but got input {sizes} output {osizes}")
+    if input.dtype not in _DTYPE_IDS or input.dtype == torch.uint8:  # Pillow has no 1-D/3-D resize to be exact against
+        raise NotImplementedError(f'"upsample_generic_Nd" not implemented for \'{_DTYPE_NAMES.get(input.dtype, str(input.dtype))}\'')
+    _require_gpu(input, name)
+    L = _lib.load()
+    x = input.contiguous()
+    dev = x.device
+    kind = _table_kind(x.dtype, None)
+    dt = _DTYPE_IDS[x.dtype]
+    if x.numel() == 0:
+        if x.shape[1] == 0:
+            raise RuntimeError(f"Non-empty {nd + 2}D data tensor expected but got a tensor with sizes {list(input.shape)}")
+        return torch.empty(list(x.shape[:2]) + osizes, dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev):
+        s = tables._stream_ptr(dev)
+        for k in range(nd - 1, -1, -1):
+            shape = list(x.shape)
+            n_in, n_out = shape[2 + k], osizes[k]
+            outer = 1
+            for v in shape[:2 + k]:
+                outer *= v
+            inner = 1
+            for v in shape[3 + k:]:
+                inner *= v
+            t = tables.get_table(filter_id, kind, n_in, n_out, align_corners, 0.0, dev)
+            ax = t.axis()
+            shape[2 + k] = n_out
+            y = torch.empty(shape, dtype=x.dtype, device=dev)
+            rc = L.aa_resample_axis_fwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), dt, outer, n_in, inner,
+                                        ctypes.byref(ax), s)
+            _lib.check(rc, name)
+            x = y
+    return x
+
+
+def linear_forward_nd(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False) -> torch.Tensor:
+    """Antialiased linear / bilinear / trilinear resize of an NCL, NCHW or NCDHW tensor."""
+    return _forward_nd(_lib.FILTER_LINEAR, "linear_forward_nd", input, output_size, align_corners)
+
+
+def cubic_forward_nd(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False) -> torch.Tensor:
+    return _forward_nd(_lib.FILTER_CUBIC, "cubic_forward_nd", input, output_size, align_corners)
+
+
+def nearest_forward_nd(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False) -> torch.Tensor:
+    return _forward_nd(_lib.FILTER_BOX, "nearest_forward_nd", input, output_size, align_corners)
 
 
 # ---- the reference's callables ---------------------------------------------------------------------------

@@ -244,8 +244,8 @@ def test_empty_batch_and_errors(aa):
         aa.linear_forward(torch.zeros(3, 8, 8, device="cuda"), [4, 4])
     with pytest.raises(RuntimeError, match="It is expected output_size equals to 2"):
         aa.linear_forward(torch.zeros(1, 3, 8, 8, device="cuda"), [4])
-    with pytest.raises(NotImplementedError, match="not implemented for 'Half'"):
-        aa.linear_forward(torch.zeros(1, 3, 8, 8, device="cuda", dtype=torch.float16), [4, 4])
+    with pytest.raises(NotImplementedError, match="not implemented for 'Int'"):
+        aa.linear_forward(torch.zeros(1, 3, 8, 8, device="cuda", dtype=torch.int32), [4, 4])
 
 
 def test_noncontiguous_input(aa):
@@ -401,3 +401,70 @@ def test_nonfinite_inputs_do_not_leak(aa):
     assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(np.isinf(got), np.isinf(exp))
     ok = np.isfinite(exp)
     assert np.array_equal(got[ok], exp[ok])
+
+
+# ------------------------------------------------------------------------------------------------ §8f: 16-bit floats, N-d
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_half_precision_is_rounded_fp32(aa, dtype, channels_last):
+    """fp16/bf16 (not dispatched by the reference): defined as  half(reference_fp32(float(x)))  — fp32 arithmetic in
+    the reference's order, fp32 intermediate, one round-to-nearest-even at the store.  Checked bit for bit against the
+    oracle run on the up-cast input."""
+    torch.manual_seed(11)
+    for filt, shape, size in (("linear", (2, 3, 61, 53), (17, 23)), ("cubic", (1, 2, 40, 64), (13, 100)), ("box", (1, 1, 33, 35), (11, 7))):
+        x = (torch.rand(shape) * 200 - 20).to(dtype)
+        exp = torch.from_numpy(oracle.forward(filt, x.float().numpy(), size)).to(dtype)
+        xg = x.cuda()
+        if channels_last:
+            xg = xg.contiguous(memory_format=torch.channels_last)
+        got = _fn(aa, filt)(xg, list(size))
+        assert got.dtype == dtype and got.is_contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+        assert torch.equal(got.cpu().view(torch.int16), exp.view(torch.int16)), (filt, shape, size)
+
+
+def _oracle_axis(filt, a, axis, n_out, align_corners=False):
+    """One separable pass along `axis` with the 2-D oracle: the axis becomes W of an [outer, inner, 1, n] image (the
+    H pass is 1 -> 1, a single tap of weight exactly 1)."""
+    moved = np.moveaxis(a, axis, -1)
+    lead = moved.shape[:-1]
+    img = np.ascontiguousarray(moved.reshape(-1, 1, 1, moved.shape[-1]))
+    out = oracle.forward(filt, img, (1, n_out), align_corners)
+    return np.moveaxis(out.reshape(*lead, n_out), -1, axis)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_1d_and_3d_front_ends(aa, dt):
+    """NCL and NCDHW: the reference's driver resamples the LAST axis first (s2.2:658); the oracle is its
+    2-D restatement applied axis by axis in that order, so results must be bit-identical."""
+    rng = np.random.default_rng(5)
+    x1 = (rng.random((3, 4, 97)) * 255).astype(dt)
+    for filt, fn in (("linear", aa.linear_forward_nd), ("cubic", aa.cubic_forward_nd), ("box", aa.nearest_forward_nd)):
+        for n_out in (31, 97, 150):
+            got = fn(_gpu(x1), [n_out]).cpu().numpy()
+            assert np.array_equal(got, _oracle_axis(filt, x1, 2, n_out)), (filt, n_out)
+    x3 = (rng.random((2, 3, 19, 23, 29)) * 255).astype(dt)
+    for filt, fn in (("linear", aa.linear_forward_nd), ("cubic", aa.cubic_forward_nd)):
+        for size in ((7, 9, 11), (19, 40, 10), (30, 23, 29)):
+            exp = x3
+            for axis in (4, 3, 2):
+                exp = _oracle_axis(filt, exp, axis, size[axis - 2])
+            got = fn(_gpu(x3), list(size)).cpu().numpy()
+            assert got.shape == (2, 3) + size and np.array_equal(got, exp), (filt, size)
+    # align_corners only changes the scale (s2.2:314-315); 4-D input goes to the 2-D path; functional wrapper
+    got = aa.linear_forward_nd(_gpu(x1), [40], True).cpu().numpy()
+    assert np.array_equal(got, _oracle_axis("linear", x1, 2, 40, True))
+    x2 = (rng.random((1, 2, 20, 30)) * 255).astype(dt)
+    assert np.array_equal(aa.linear_forward_nd(_gpu(x2), [7, 9]).cpu().numpy(), oracle.forward("linear", x2, (7, 9)))
+    from interpolate_antialiasing_amd.functional import interpolate_aa
+    assert np.array_equal(interpolate_aa(_gpu(x3), (7, 9, 11), "trilinear").cpu().numpy(), aa.linear_forward_nd(_gpu(x3), [7, 9, 11]).cpu().numpy())
+
+
+def test_nd_matches_torch_upstream(aa):
+    """Independent cross-check (never the implementation): PyTorch's own antialiased interpolate is 2-D only, so compare
+    the 1-D front-end with F.interpolate on an [N,C,1,L] view (its H pass is an exact identity)."""
+    import torch.nn.functional as F
+
+    x = torch.rand(2, 3, 211, device="cuda", dtype=torch.float64)
+    got = aa.linear_forward_nd(x, [64])
+    ref = F.interpolate(x[:, :, None, :], size=(1, 64), mode="bilinear", antialias=True, align_corners=False)[:, :, 0, :]
+    assert torch.allclose(got, ref, rtol=0, atol=1e-12)

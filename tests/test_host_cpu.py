@@ -65,8 +65,12 @@ def test_argument_errors_without_gpu():
         aa.cubic_forward(x[0], [4, 4])
     with pytest.raises(RuntimeError, match="It is expected output_size equals to 2"):
         aa.nearest_forward(x, [4, 4, 4])
-    with pytest.raises(NotImplementedError, match="not implemented for 'Half'"):
-        aa.linear_forward(x.half(), [4, 4])
+    with pytest.raises(NotImplementedError, match="not implemented for 'Int'"):
+        aa.linear_forward(x.int(), [4, 4])
+    with pytest.raises(RuntimeError, match="It is expected output_size equals to 3"):
+        aa.linear_forward_nd(torch.zeros(1, 2, 4, 4, 4), [4, 4])
+    with pytest.raises(NotImplementedError, match="not implemented for 'Byte'"):
+        aa.linear_forward_nd(torch.zeros(1, 2, 9, dtype=torch.uint8), [4])
     # the product is the HIP path only: CPU tensors fail loudly, nothing falls back to a CPU implementation
     with pytest.raises(_lib.AAInterpError, match="no CPU implementation"):
         aa.linear_forward(x, [4, 4])
