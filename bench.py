@@ -114,6 +114,57 @@ def cpu_baseline(seconds: float = 12.0):
     }
 
 
+def secondary_configs(dev):
+    """Short timings (rank 0, N=1, after the headline's timed region) of the other BASELINE.json configs, so that every
+    round's BENCH json carries them: algorithmic GB/s = (input + output bytes) / event time.  Not the headline metric."""
+    from interpolate_antialiasing_amd import _lib, extension_interpolate as aa
+
+    def timed(fn, reps=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    res = []
+    torch.manual_seed(1)
+
+    def add(name, fn, nbytes):
+        try:
+            ms = timed(fn)
+            res.append({"workload": name, "ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "variant": _lib.last_variant()})
+        except Exception as e:  # a secondary line must never take the headline down with it
+            res.append({"workload": name, "error": str(e)[:200]})
+        torch.cuda.empty_cache()
+
+    x = torch.rand(256, 3, 438, 906, device=dev) * 255
+    add("configs[0] on GPU: fp32 NCHW [256,3,438,906]->[196,320] bilinear", lambda: aa.linear_forward(x, [196, 320]),
+        256 * 3 * 4 * (438 * 906 + 196 * 320))
+    del x
+    x = torch.rand(64, 3, 1024, 1024, device=dev) * 255
+    add("configs[2]: fp32 NCHW [64,3,1024,1024]->[224,224] bicubic", lambda: aa.cubic_forward(x, [224, 224]),
+        64 * 3 * 4 * (1024 * 1024 + 224 * 224))
+    del x
+    x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+    add("configs[3] per-GPU shard: uint8 channels_last [1024,3,906,438]->[320,196] bilinear", lambda: aa.linear_forward(x, [320, 196]),
+        1024 * 3 * (906 * 438 + 320 * 196))
+    del x
+    g = torch.randn(256, 3, 196, 320, device=dev)
+    add("configs[4] batched: backward fp32 grad [256,3,196,320]->[256,3,438,906], gather form (true adjoint)",
+        lambda: aa.linear_backward(g, [196, 320], [256, 3, 438, 906]), 256 * 3 * 4 * (438 * 906 + 196 * 320))
+    g1 = torch.randn(1, 3, 196, 320, device=dev)
+    add("configs[4] as written: backward fp32 grad [1,3,196,320]->[1,3,438,906], gather form (latency)",
+        lambda: aa.linear_backward(g1, [196, 320], [1, 3, 438, 906]), 3 * 4 * (438 * 906 + 196 * 320))
+    x1 = torch.randint(0, 256, (1, 438, 906, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+    add("configs[1] as written: uint8 channels_last [1,3,438,906]->[196,320] (latency)", lambda: aa.linear_forward(x1, [196, 320]),
+        3 * (438 * 906 + 196 * 320))
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +173,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short timings of the other BASELINE configs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,6 +253,8 @@ def main():
                          "kernel": variant, "kernel_ms": round(kern_ms, 4), "alg_bytes_per_launch": alg_bytes_img * B,
                          "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4)},
         }
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
