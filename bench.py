@@ -152,6 +152,9 @@ def secondary_configs(dev):
     x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
     add("configs[3] per-GPU shard: uint8 channels_last [1024,3,906,438]->[320,196] bilinear", lambda: aa.linear_forward(x, [320, 196]),
         1024 * 3 * (906 * 438 + 320 * 196))
+    x = x.contiguous()
+    add("uint8 NCHW (planar) [1024,3,906,438]->[320,196] bilinear", lambda: aa.linear_forward(x, [320, 196]),
+        1024 * 3 * (906 * 438 + 320 * 196))
     del x
     g = torch.randn(256, 3, 196, 320, device=dev)
     add("configs[4] batched: backward fp32 grad [256,3,196,320]->[256,3,438,906], gather form (true adjoint)",

@@ -51,6 +51,7 @@ struct FusedU8V3Params {
   int sc_off;      // scatter section of the H table (bytes from table start): one 8-int record per input row
   int in_mis;      // (input pointer & 15): the kernel gets the pointer rounded down to 16 B
   unsigned long long img_in_bytes, img_out_bytes, total_in_bytes, total_out_bytes;
+  long long n_images;  // = N for channels_last, N*C for planar input
 };
 
 __device__ inline unsigned pack4_clip8(int a0, int a1, int a2, int a3) {  // semantics: see aa_fused_u8.hip
@@ -170,6 +171,10 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     store_voff = (unsigned)(ox0 * 3 + (lane >> 2) * 12 + q * 4);
     store_lane = (q != 3) && ((lane | 3) < bw);  // bw is a multiple of 4: the whole quad is in range or none of it
     perm_sel = q == 0 ? 0x04020100u : (q == 1 ? 0x05040201u : 0x06050402u);
+  } else if constexpr (C == 1) {
+    // planar bytes: a quad of lanes holds 4 consecutive bytes = 1 dword, stored by the quad's first lane
+    store_voff = (unsigned)(ox0 + lane);
+    store_lane = ((lane & 3) == 0) && ((lane | 3) < bw);
   } else {
     store_voff = (unsigned)((ox0 + lane) * 4);
     store_lane = active;
@@ -238,6 +243,13 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       const unsigned dw = __builtin_amdgcn_perm(nb, t, perm_sel);
       if (store_lane && (AA_V3_ABL != 1 || dw == 0x12345678u))
         __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+    } else if constexpr (C == 1) {
+      const unsigned t = pack4_clip8(A[0][0], A[0][0], A[0][0], A[0][0]);  // the lane's byte, replicated
+      const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x55 /*quad_perm:[1,1,1,1]*/, 0xF, 0xF, false);
+      const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xAA /*quad_perm:[2,2,2,2]*/, 0xF, 0xF, false);
+      const unsigned n3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xFF /*quad_perm:[3,3,3,3]*/, 0xF, 0xF, false);
+      const unsigned dw = (t & 0x000000ffu) | (n1 & 0x0000ff00u) | (n2 & 0x00ff0000u) | (n3 & 0xff000000u);
+      if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
     } else {
       const unsigned dw = pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][C - 1]);
       if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
@@ -408,8 +420,8 @@ int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
     blocks_per_cu[spb] = nb < 1 ? 1 : nb;
   }
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
-  p.ybands = pick_ybands(q.N * sgroups, (double)aa_device_cu_count() * blocks_per_cu[spb], taps_h, q.H, q.oH);
-  const int64_t grid = q.N * (int64_t)p.ybands * sgroups;
+  p.ybands = pick_ybands(p.n_images * sgroups, (double)aa_device_cu_count() * blocks_per_cu[spb], taps_h, q.H, q.oH);
+  const int64_t grid = p.n_images * (int64_t)p.ybands * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk,
                      q.stream, (const uint8_t *)q.in - p.in_mis, (uint8_t *)q.out, (const char *)q.aw.table_dev,
@@ -472,10 +484,13 @@ int round_tw(int taps) {
 }  // namespace
 
 int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
-  if (q.dtype != AA_U8 || q.layout != AA_NHWC) return 0;
+  if (q.dtype != AA_U8) return 0;
   if (q.ah.kind != AA_TABLE_PIL || q.aw.kind != AA_TABLE_PIL) return 0;
-  const int C = (int)q.C;
-  if (C != 3 && C != 4) return 0;
+  // channels_last with 3 or 4 interleaved channels, or planar bytes: NCHW is N*C single-channel images
+  const bool planar = q.layout == AA_NCHW || q.C == 1;
+  const int C = planar ? 1 : (int)q.C;
+  const int64_t NI = planar ? q.N * q.C : q.N;  // images the kernel sees
+  if (C != 1 && C != 3 && C != 4) return 0;
   // the in-register vertical pass needs the H table's scatter section and at most 4 open output rows
   if (q.ah.scatter_off <= 0 || q.ah.scatter_max <= 0 || q.ah.scatter_max > 4) return 0;
   if (q.H < q.oH) return 0;  // down-scaling (or equal) in H: output rows complete one at a time, in order
@@ -496,8 +511,9 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   p.img_in_bytes = (unsigned long long)q.H * q.W * C;
   p.img_out_bytes = (unsigned long long)q.oH * q.oW * C;
   p.in_mis = (int)((uintptr_t)q.in & 15);
-  p.total_in_bytes = p.img_in_bytes * (unsigned long long)q.N + (unsigned long long)p.in_mis;
-  p.total_out_bytes = p.img_out_bytes * (unsigned long long)q.N;
+  p.total_in_bytes = p.img_in_bytes * (unsigned long long)NI + (unsigned long long)p.in_mis;
+  p.total_out_bytes = p.img_out_bytes * (unsigned long long)NI;
+  p.n_images = NI;
   p.sc_off = q.ah.scatter_off;
   p.nstrips = (int)((q.oW + 63) / 64);
   p.strip_w = (int)(((q.oW + p.nstrips - 1) / p.nstrips + 3) & ~3);  // balanced strips (196 -> 4 x 52, not 3 x 64 + 4)
@@ -521,7 +537,9 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   const int64_t grid = 0;  // decided per kernel instantiation (launch_k)
   p.ybands = 1;
 
-  const int rc = (C == 3) ? dispatch_tw<3>(tw, q.ah.scatter_max, p, q, lds, grid) : dispatch_tw<4>(tw, q.ah.scatter_max, p, q, lds, grid);
-  if (rc == 1) *variant = "fused_u8_nhwc_pil_v3";
+  const int rc = C == 3   ? dispatch_tw<3>(tw, q.ah.scatter_max, p, q, lds, grid)
+                 : C == 4 ? dispatch_tw<4>(tw, q.ah.scatter_max, p, q, lds, grid)
+                          : dispatch_tw<1>(tw, q.ah.scatter_max, p, q, lds, grid);
+  if (rc == 1) *variant = planar ? "fused_u8_planar_pil_v3" : "fused_u8_nhwc_pil_v3";
   return rc;
 }

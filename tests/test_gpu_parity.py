@@ -336,6 +336,9 @@ def test_fused_kernels_match_generic_at_full_size(aa):
     cases += [(aa.linear_forward, x8t, [320, 196])]
     x4 = torch.randint(0, 256, (5, 300, 500, 4), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)   # C = 4
     cases += [(aa.linear_forward, x4, [111, 204]), (aa.cubic_forward, x4, [150, 252])]
+    x8p = torch.randint(0, 256, (12, 3, 438, 906), dtype=torch.uint8, device="cuda")                     # planar (NCHW) bytes
+    cases += [(aa.linear_forward, x8p, [196, 320]), (aa.cubic_forward, x8p, [196, 320]), (aa.nearest_forward, x8p[:2], [100, 204]),
+              (aa.linear_forward, x8p[:, :1], [438, 320]), (aa.linear_forward, x8p[:3], [196, 322])]
     xf = torch.rand(6, 3, 438, 906, device="cuda") * 255
     cases += [(aa.linear_forward, xf, [196, 320]), (aa.cubic_forward, xf, [196, 320]), (aa.nearest_forward, xf, [196, 320])]
     xc = torch.rand(3, 3, 1024, 1024, device="cuda") * 255                                              # config 2 shape
@@ -361,7 +364,7 @@ def test_fused_kernels_match_generic_at_full_size(aa):
             assert torch.equal(y1, y0), (getattr(fn, "__name__", "backward"), tuple(x.shape), size)
     finally:
         _lib.set_fused(1)
-    assert {"fused_u8_nhwc_pil_v3", "fused_f32_nchw", "fused_f32_nchw_up"} <= fused_seen, fused_seen
+    assert {"fused_u8_nhwc_pil_v3", "fused_u8_planar_pil_v3", "fused_f32_nchw", "fused_f32_nchw_up"} <= fused_seen, fused_seen
 
 
 def test_all_fused_generations_agree(aa):
