@@ -471,3 +471,37 @@ def test_nd_matches_torch_upstream(aa):
     got = aa.linear_forward_nd(x, [64])
     ref = F.interpolate(x[:, :, None, :], size=(1, 64), mode="bilinear", antialias=True, align_corners=False)[:, :, 0, :]
     assert torch.allclose(got, ref, rtol=0, atol=1e-12)
+
+
+def test_rccl_broadcast_path_single_rank(aa):
+    """The multi-GPU path's only collective (rank 0's packed tables -> everyone, then cached) through the REAL backend:
+    a one-rank RCCL group on this box exercises the calls bench.py makes at N > 1 (group creation bound to the device,
+    descriptor + payload broadcasts of GPU buffers, the MAX/SUM reductions).  World-size-2 logic runs under gloo in the
+    CPU suite."""
+    import socket
+
+    import torch.distributed as dist
+    from interpolate_antialiasing_amd import _lib, sharding, tables
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        t = tables.get_table(_lib.FILTER_LINEAR, _lib.TABLE_PIL, 906, 320, False, 0.0, dev)
+        r = sharding.broadcast_table(t, src=0, device=dev)
+        assert r is t
+        v = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        n = torch.tensor([7], dtype=torch.int64, device=dev)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        dist.barrier()
+        assert float(v.item()) == 1.5 and int(n.item()) == 7
+        th, tw = sharding.prepare_tables(_lib.FILTER_LINEAR, _lib.TABLE_PIL, (438, 906), (196, 320), False, dev)
+        assert (th.in_size, th.out_size, tw.in_size, tw.out_size) == (438, 196, 906, 320)
+    finally:
+        dist.destroy_process_group()
