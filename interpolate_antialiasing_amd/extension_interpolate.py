@@ -32,7 +32,8 @@ import torch
 from . import _lib, tables
 
 __all__ = ["linear_forward", "nearest_forward", "cubic_forward", "linear_backward", "cubic_backward",
-           "nearest_backward", "forward", "linear_forward_nd", "cubic_forward_nd", "nearest_forward_nd", "set_uint8_mode",
+           "nearest_backward", "forward", "linear_forward_nd", "cubic_forward_nd", "nearest_forward_nd", "linear_backward_nd",
+           "cubic_backward_nd", "set_uint8_mode",
            "get_uint8_mode", "last_variant"]
 
 _uint8_mode = "pil"
@@ -101,8 +102,19 @@ def _require_gpu(x: torch.Tensor, what: str):
             "MI355X HIP path only and has no CPU implementation.")
 
 
+def _user_scales(scale_factors, n: int):
+    """ATen's optional per-axis scale factors (`scale_h`, `scale_w` of upsample_*2d; the reference hard-wires none,
+    s2.2:11-13).  A given factor s replaces in/out by 1/s in area_pixel_compute_scale unless align_corners."""
+    if scale_factors is None:
+        return [0.0] * n
+    sf = [float(v) if v is not None else 0.0 for v in scale_factors]
+    if len(sf) != n or any(v < 0 for v in sf):
+        raise RuntimeError(f"scale_factors must hold {n} positive values, got {list(scale_factors)}")
+    return sf
+
+
 def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequence[int], align_corners: bool,
-             uint8_mode: Optional[str] = None) -> torch.Tensor:
+             uint8_mode: Optional[str] = None, scale_factors: Optional[Sequence[float]] = None) -> torch.Tensor:
     if not isinstance(input, torch.Tensor):
         raise TypeError(f"{name}(): argument 'input' must be Tensor")
     n, c, h, w, oh, ow = _check_sizes(input.shape, output_size)
@@ -116,14 +128,17 @@ def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequen
     kind = _table_kind(x.dtype, uint8_mode)
     if kind == _lib.TABLE_PIL and align_corners:
         raise NotImplementedError("uint8_mode='pil' has no align_corners (Pillow has none); use uint8_mode='harness'")
+    sh, sw = _user_scales(scale_factors, 2)
+    if kind == _lib.TABLE_PIL and (sh or sw):
+        raise NotImplementedError("uint8_mode='pil' has no scale factors (Pillow derives the scale from the sizes)")
     dev = x.device
     mf = torch.channels_last if layout == _lib.NHWC else torch.contiguous_format
     out = torch.empty((n, c, oh, ow), dtype=x.dtype, device=dev, memory_format=mf)
     if n == 0:
         return out
     with torch.cuda.device(dev):
-        th = tables.get_table(filter_id, kind, h, oh, align_corners, 0.0, dev)
-        tw = tables.get_table(filter_id, kind, w, ow, align_corners, 0.0, dev)
+        th = tables.get_table(filter_id, kind, h, oh, align_corners, sh, dev)
+        tw = tables.get_table(filter_id, kind, w, ow, align_corners, sw, dev)
         ah, aw = th.axis(), tw.axis()
         dt = _DTYPE_IDS[x.dtype]
         ws_bytes = L.aa_workspace_bytes(dt, layout, n, c, h, w, oh, ow, ctypes.byref(ah), ctypes.byref(aw))
@@ -234,6 +249,64 @@ def _forward_nd(filter_id: int, name: str, input: torch.Tensor, output_size: Seq
     return x
 
 
+def _backward_nd(filter_id: int, name: str, grad_output: torch.Tensor, output_size: Sequence[int], input_size: Sequence[int],
+                 align_corners: bool) -> torch.Tensor:
+    """True adjoint of `_forward_nd`: one pass per axis with the transposed table of that axis (the 1-D adjoints act on
+    different axes and commute).  The reference's backward header carries 1-D/3-D loops as well
+    (aa_interpolation_backward_impl.h:58-78,110-150), non-antialiased like its 2-D one."""
+    nd = len(input_size) - 2
+    if nd not in (1, 2, 3) or len(output_size) != nd:
+        raise RuntimeError(f"It is expected input_size equals to 3, 4 or 5 and output_size to match, but got {list(input_size)} "
+                           f"and {list(output_size)}")
+    if nd == 2:
+        return _backward(filter_id, name, grad_output, output_size, input_size, align_corners)
+    full = [int(v) for v in input_size[:2]] + [int(v) for v in output_size]
+    if list(grad_output.shape) != full:
+        raise RuntimeError(f"Expected grad_output to have the same shape as output; output.shape = {full} but got "
+                           f"grad_output.shape = {list(grad_output.shape)}")
+    if grad_output.dtype not in (torch.float32, torch.float64):
+        raise NotImplementedError(f'"ti_upsample_bilinear2d_backward_cpu" not implemented for '
+                                  f'\'{_DTYPE_NAMES.get(grad_output.dtype, str(grad_output.dtype))}\'')
+    _require_gpu(grad_output, name)
+    L = _lib.load()
+    g = grad_output.contiguous()
+    dev = g.device
+    kind = _lib.TABLE_F32 if g.dtype == torch.float32 else _lib.TABLE_F64
+    dt = _DTYPE_IDS[g.dtype]
+    if g.numel() == 0:
+        return torch.zeros([int(v) for v in input_size], dtype=g.dtype, device=dev)
+    with torch.cuda.device(dev):
+        s = tables._stream_ptr(dev)
+        for k in range(nd):
+            shape = list(g.shape)
+            n_out_fwd, n_in_fwd = shape[2 + k], int(input_size[2 + k])
+            outer = 1
+            for v in shape[:2 + k]:
+                outer *= v
+            inner = 1
+            for v in shape[3 + k:]:
+                inner *= v
+            fwd = tables.get_table(filter_id, kind, n_in_fwd, n_out_fwd, align_corners, 0.0, dev)
+            ax = tables.get_transposed_table(fwd).axis()  # maps n_out_fwd -> n_in_fwd
+            shape[2 + k] = n_in_fwd
+            y = torch.empty(shape, dtype=g.dtype, device=dev)
+            rc = L.aa_resample_axis_fwd(ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(y.data_ptr()), dt, outer, n_out_fwd, inner,
+                                        ctypes.byref(ax), s)
+            _lib.check(rc, name)
+            g = y
+    return g
+
+
+def linear_backward_nd(grad_output: torch.Tensor, output_size: Sequence[int], input_size: Sequence[int],
+                       align_corners: bool = False) -> torch.Tensor:
+    return _backward_nd(_lib.FILTER_LINEAR, "linear_backward_nd", grad_output, output_size, input_size, align_corners)
+
+
+def cubic_backward_nd(grad_output: torch.Tensor, output_size: Sequence[int], input_size: Sequence[int],
+                      align_corners: bool = False) -> torch.Tensor:
+    return _backward_nd(_lib.FILTER_CUBIC, "cubic_backward_nd", grad_output, output_size, input_size, align_corners)
+
+
 def linear_forward_nd(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False) -> torch.Tensor:
     """Antialiased linear / bilinear / trilinear resize of an NCL, NCHW or NCDHW tensor."""
     return _forward_nd(_lib.FILTER_LINEAR, "linear_forward_nd", input, output_size, align_corners)
@@ -249,21 +322,21 @@ def nearest_forward_nd(input: torch.Tensor, output_size: Sequence[int], align_co
 
 # ---- the reference's callables ---------------------------------------------------------------------------
 def linear_forward(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False, *,
-                   uint8_mode: Optional[str] = None) -> torch.Tensor:
+                   uint8_mode: Optional[str] = None, scale_factors: Optional[Sequence[float]] = None) -> torch.Tensor:
     """Anti-Aliased Linear Interpolation forward (s2.2/extension_interpolate.cpp:7-14,47)."""
-    return _forward(_lib.FILTER_LINEAR, "linear_forward", input, output_size, align_corners, uint8_mode)
+    return _forward(_lib.FILTER_LINEAR, "linear_forward", input, output_size, align_corners, uint8_mode, scale_factors)
 
 
 def nearest_forward(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False, *,
-                    uint8_mode: Optional[str] = None) -> torch.Tensor:
+                    uint8_mode: Optional[str] = None, scale_factors: Optional[Sequence[float]] = None) -> torch.Tensor:
     """Anti-Aliased "Nearest" (really: box filter) forward (s2.2/extension_interpolate.cpp:26-33,48)."""
-    return _forward(_lib.FILTER_BOX, "nearest_forward", input, output_size, align_corners, uint8_mode)
+    return _forward(_lib.FILTER_BOX, "nearest_forward", input, output_size, align_corners, uint8_mode, scale_factors)
 
 
 def cubic_forward(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False, *,
-                  uint8_mode: Optional[str] = None) -> torch.Tensor:
+                  uint8_mode: Optional[str] = None, scale_factors: Optional[Sequence[float]] = None) -> torch.Tensor:
     """Anti-Aliased Cubic Interpolation forward (s2.2/extension_interpolate.cpp:35-42,49)."""
-    return _forward(_lib.FILTER_CUBIC, "cubic_forward", input, output_size, align_corners, uint8_mode)
+    return _forward(_lib.FILTER_CUBIC, "cubic_forward", input, output_size, align_corners, uint8_mode, scale_factors)
 
 
 def linear_backward(grad_output: torch.Tensor, output_size: Sequence[int], input_size: Sequence[int],

@@ -505,3 +505,65 @@ def test_rccl_broadcast_path_single_rank(aa):
         assert (th.in_size, th.out_size, tw.in_size, tw.out_size) == (438, 196, 906, 320)
     finally:
         dist.destroy_process_group()
+
+
+def test_explicit_scale_factors(aa):
+    """ATen's optional scale factors (the reference's binding hard-wires none, s2.2:11-13): a given factor s
+    makes the scale 1/s instead of in/out (area_pixel_compute_scale), which moves windows and weights.  Tables bit-exact
+    against the oracle's restatement of that rule; the forward result against those tables applied in the reference's
+    order (tap 0 first, product and sum rounded separately), W pass then H pass."""
+    from interpolate_antialiasing_amd import _lib, tables
+
+    rng = np.random.default_rng(9)
+    x = (rng.random((2, 3, 50, 70)) * 255).astype(np.float32)
+    oh, ow, sh, sw = 21, 31, 0.4, 0.45  # floor(50 * 0.4) = 20 != 21: the factor, not the size ratio, sets the scale
+    for filt in ("linear", "cubic"):
+        tabs = []
+        for n_in, n_out, s in ((50, oh, sh), (70, ow, sw)):
+            k, xmin, xsize, w = oracle.weights(filt, n_in, n_out, False, np.float32, scale=s)
+            t = tables.build_table(oracle.FILTERS[filt], _lib.TABLE_F32, n_in, n_out, False, s, torch.device("cuda"))
+            dxmin, dxsize, dw = t.unpack()
+            assert t.ksize == k and np.array_equal(dxmin, xmin) and np.array_equal(dxsize, xsize) and np.array_equal(dw, w)
+            k0, xmin0, _, _ = oracle.weights(filt, n_in, n_out, False, np.float32)
+            assert k0 != k or not np.array_equal(xmin0, xmin)  # the factor really changes the table
+            tabs.append((xmin, xsize, w))
+
+        def apply(a, tab, n_out):  # along the last axis
+            xmin, xsize, w = tab
+            out = np.empty(a.shape[:-1] + (n_out,), np.float32)
+            for o in range(n_out):
+                acc = a[..., xmin[o]] * w[o, 0]
+                for j in range(1, max(int(xsize[o]), 1)):
+                    acc = acc + a[..., xmin[o] + j] * w[o, j]
+                out[..., o] = acc
+            return out
+
+        mid = apply(x, tabs[1], ow)                                # W pass first (s2.2:658)
+        exp = np.swapaxes(apply(np.swapaxes(mid, 2, 3), tabs[0], oh), 2, 3)
+        got = _fn(aa, filt)(_gpu(x), [oh, ow], False, scale_factors=[sh, sw]).cpu().numpy()
+        assert np.array_equal(got, exp), filt
+    with pytest.raises(NotImplementedError, match="no scale factors"):
+        aa.linear_forward(torch.zeros(1, 3, 8, 8, dtype=torch.uint8, device="cuda"), [4, 4], scale_factors=[0.5, 0.5])
+
+
+def test_nd_backward_is_the_adjoint(aa):
+    """1-D / 3-D backward: <A x, y> == <x, A^T y> in fp64 for the front-ends' forward A (size-independent property), and
+    the 1-D case against autograd of PyTorch's own antialiased interpolate on an [N,C,1,L] view."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(6)
+    for fwd, bwd, shape, size in ((aa.linear_forward_nd, aa.linear_backward_nd, (2, 3, 57), (19,)),
+                                  (aa.cubic_forward_nd, aa.cubic_backward_nd, (1, 2, 40), (90,)),
+                                  (aa.linear_forward_nd, aa.linear_backward_nd, (2, 2, 11, 13, 17), (5, 20, 7)),
+                                  (aa.cubic_forward_nd, aa.cubic_backward_nd, (1, 1, 9, 8, 30), (9, 3, 11))):
+        x = torch.randn(shape, dtype=torch.float64, device="cuda")
+        y = torch.randn(shape[:2] + size, dtype=torch.float64, device="cuda")
+        lhs = (fwd(x, list(size)) * y).sum()
+        rhs = (x * bwd(y, list(size), list(shape))).sum()
+        assert abs(lhs.item() - rhs.item()) <= 1e-10 * max(1.0, abs(lhs.item())), (shape, size)
+    x = torch.randn(2, 3, 211, dtype=torch.float64, device="cuda", requires_grad=True)
+    g = torch.randn(2, 3, 64, dtype=torch.float64, device="cuda")
+    ref = F.interpolate(x[:, :, None, :], size=(1, 64), mode="bilinear", antialias=True, align_corners=False)[:, :, 0, :]
+    ref.backward(g)
+    got = aa.linear_backward_nd(g, [64], [2, 3, 211])
+    assert torch.allclose(got, x.grad, rtol=0, atol=1e-12)
