@@ -457,6 +457,8 @@ int launch(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, i
   if (g_group3 == 4) return launch_g<C, TW, 4>(maxc, p, q, lds, grid);
   if (g_group3 == 6) return launch_g<C, TW, 6>(maxc, p, q, lds, grid);
   if (g_group3 == 10) return launch_g<C, TW, 10>(maxc, p, q, lds, grid);
+  if (g_group3 == 12) return launch_g<C, TW, 12>(maxc, p, q, lds, grid);
+  if (g_group3 == 16) return launch_g<C, TW, 16>(maxc, p, q, lds, grid);
 #endif
   return launch_g<C, TW, 8>(maxc, p, q, lds, grid);
 }
