@@ -165,6 +165,20 @@ def secondary_configs(dev):
     x1 = torch.randint(0, 256, (1, 438, 906, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
     add("configs[1] as written: uint8 channels_last [1,3,438,906]->[196,320] (latency)", lambda: aa.linear_forward(x1, [196, 320]),
         3 * (438 * 906 + 196 * 320))
+    try:  # the same B=1 call replayed from a HIP graph (what a latency-bound server would do)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            aa.linear_forward(x1, [196, 320])
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            aa.linear_forward(x1, [196, 320])
+        ms = timed(graph.replay, reps=200)
+        res.append({"workload": "configs[1] as written, HIP-graph replay (latency)", "ms": round(ms, 4),
+                    "GB/s": round(3 * (438 * 906 + 196 * 320) / ms / 1e6, 1), "variant": "fused_u8_nhwc_pil_v3 (graph)"})
+    except Exception as e:
+        res.append({"workload": "configs[1] as written, HIP-graph replay (latency)", "error": str(e)[:200]})
     return res
 
 

@@ -567,3 +567,32 @@ def test_nd_backward_is_the_adjoint(aa):
     ref.backward(g)
     got = aa.linear_backward_nd(g, [64], [2, 3, 211])
     assert torch.allclose(got, x.grad, rtol=0, atol=1e-12)
+
+
+def test_hip_graph_capture_and_replay(aa):
+    """The launches are stream-ordered and allocation-free once the tables are cached, so a latency-bound caller can
+    capture them in a HIP graph (torch.cuda.CUDAGraph) and replay: same bytes as the eager call, for new input data."""
+    torch.manual_seed(12)
+    xs = torch.randint(0, 256, (2, 438, 906, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
+    gs = torch.randn(2, 3, 196, 320, device="cuda")
+    aa.linear_forward(xs, [196, 320])                      # builds and caches the tables (the only synchronising step)
+    aa.linear_backward(gs, [196, 320], [2, 3, 438, 906])
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                          # warm-up on the capture stream, as torch requires
+        aa.linear_forward(xs, [196, 320])
+        aa.linear_backward(gs, [196, 320], [2, 3, 438, 906])
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = aa.linear_forward(xs, [196, 320])
+        gi = aa.linear_backward(gs, [196, 320], [2, 3, 438, 906])
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        xs.copy_(torch.randint(0, 256, (2, 438, 906, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2))
+        gs.copy_(torch.randn(2, 3, 196, 320, device="cuda"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, aa.linear_forward(xs, [196, 320]))
+        assert torch.equal(gi, aa.linear_backward(gs, [196, 320], [2, 3, 438, 906]))
