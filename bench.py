@@ -152,6 +152,8 @@ def secondary_configs(dev):
     x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
     add("configs[3] per-GPU shard: uint8 channels_last [1024,3,906,438]->[320,196] bilinear", lambda: aa.linear_forward(x, [320, 196]),
         1024 * 3 * (906 * 438 + 320 * 196))
+    add("configs[3] shard in the reference harness's uint8 semantics (float(), fp32 op, truncating byte())",
+        lambda: aa.linear_forward(x, [320, 196], uint8_mode="harness"), 1024 * 3 * (906 * 438 + 320 * 196))
     x = x.contiguous()
     add("uint8 NCHW (planar) [1024,3,906,438]->[320,196] bilinear", lambda: aa.linear_forward(x, [320, 196]),
         1024 * 3 * (906 * 438 + 320 * 196))

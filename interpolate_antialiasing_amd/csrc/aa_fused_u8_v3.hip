@@ -82,7 +82,10 @@ __device__ inline void wait_vmcnt(int n) {  // rounding n DOWN only waits longer
 // NONNEG: no negative weights (triangle / box): the horizontal-pass sum cannot leave [0, 255.5], so Pillow's clip8 of the
 //         intermediate is a plain shift.  PERIODIC: G*row_bytes is a multiple of 16, so the 16-byte phase of a staged
 //         row depends only on its stage slot and the per-slot LDS window addresses are loop invariants.
-template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC>
+// FLT: the reference harness's uint8 semantics instead of Pillow's (AA_TABLE_F32 tables): bytes are converted to fp32,
+//      both passes run in fp32 with separately rounded product and sum in tap order (the intermediate is never rounded),
+//      the result is clamped to [0,255] and truncated (test.py:52-58,72,75).  Registers hold float bit patterns.
+template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC, bool FLT = false>
 __global__ void __launch_bounds__(512)
 fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const char *__restrict__ tab_w,
                         const char *__restrict__ tab_h, const FusedU8V3Params p) {
@@ -135,7 +138,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   for (int j = 0; j < TW; j++) {
     const int src = j - lead;
     int w = (src >= 0 && src < xs && src < p.ksize_w) ? kw[(size_t)ox * p.ksize_w + src] : 0;
-    wreg[j] = (w << 8) >> 8;  // 24-bit operand for v_mul_i32_i24
+    wreg[j] = FLT ? w : (w << 8) >> 8;  // 24-bit operand for v_mul_i32_i24 (FLT: the float's bit pattern, 0 = +0.0f)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table loads done: from here on vmcnt counts DMAs and stores
   const int seg_first = __builtin_amdgcn_readfirstlane(start * C);  // lane 0 is always active
@@ -188,7 +191,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
   for (int k = 0; k < MAXC; k++)
 #pragma unroll
-    for (int c = 0; c < C; c++) A[k][c] = 1 << 21;
+    for (int c = 0; c < C; c++) A[k][c] = FLT ? 0 : 1 << 21;
   int o_base = oy0;
 
   auto dma = [&](unsigned a_row, int slot) {
@@ -236,9 +239,15 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     for (int k = 0; k < MAXC; k++) s.w[k] = __builtin_amdgcn_readfirstlane(rec[2 + k]);
     return s;
   };
+  auto trunc8 = [&](int bits) -> unsigned {  // harness: clamp to [0,255], truncating conversion (generic Store<uint8_t,float>)
+    float a = __int_as_float(bits);
+    a = a < 0.f ? 0.f : (a > 255.f ? 255.f : a);
+    return (unsigned)(int)a;
+  };
   auto emit = [&](int oy) {  // accumulator set 0 is complete: clip, pack, merge quads, store; then slide the sets down
     if constexpr (C == 3) {
-      const unsigned t = pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][2]);
+      const unsigned t = FLT ? (trunc8(A[0][0]) | (trunc8(A[0][1]) << 8) | (trunc8(A[0][2]) << 16))
+                             : pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][2]);
       const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xF, 0xF, false);
       const unsigned dw = __builtin_amdgcn_perm(nb, t, perm_sel);
       if (store_lane && (AA_V3_ABL != 1 || dw == 0x12345678u))
@@ -251,7 +260,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       const unsigned dw = (t & 0x000000ffu) | (n1 & 0x0000ff00u) | (n2 & 0x00ff0000u) | (n3 & 0xff000000u);
       if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
     } else {
-      const unsigned dw = pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][C - 1]);
+      const unsigned dw = FLT ? (trunc8(A[0][0]) | (trunc8(A[0][1]) << 8) | (trunc8(A[0][2]) << 16) | (trunc8(A[0][C - 1]) << 24))
+                              : pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][C - 1]);
       if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
     }
 #pragma unroll
@@ -259,7 +269,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
       for (int c = 0; c < C; c++) A[k][c] = A[k + 1][c];
 #pragma unroll
-    for (int c = 0; c < C; c++) A[MAXC - 1][c] = 1 << 21;
+    for (int c = 0; c < C; c++) A[MAXC - 1][c] = FLT ? 0 : 1 << 21;
   };
   // one input row: horizontal pass from the fetched window, then scatter into the open output rows
   // the window of the CURRENT row, realigned; consumes the LDS reads issued one row earlier
@@ -269,21 +279,41 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   };
   auto row_step = [&](const unsigned (&v)[NV], const Scatter &sc) {
     if (AA_V3_ABL == 6) return;
-    int acc[C];
+    int h[C];  // the horizontal-pass result of this row: Pillow's uint8 intermediate, or (FLT) the float's bits
+    if constexpr (FLT) {
+      float accf[C];
 #pragma unroll
-    for (int c = 0; c < C; c++) acc[c] = AA_V3_ABL == 5 ? (int)v[c] : 1 << 21;
+      for (int j = 0; j < TW; j++) {
 #pragma unroll
-    for (int j = 0; j < (AA_V3_ABL == 5 ? 0 : TW); j++) {
-#pragma unroll
-      for (int c = 0; c < C; c++) {
-        const int bi = j * C + c;
-        const int px = (int)((v[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
-        acc[c] += px * wreg[j];
+        for (int c = 0; c < C; c++) {
+          const int bi = j * C + c;
+          const float px = (float)((v[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
+          const float prod = px * __int_as_float(wreg[j]);  // taps outside the window have weight +0.0: adding their
+          accf[c] = j == 0 ? prod : accf[c] + prod;          // products never changes a value (bytes are finite)
+        }
       }
-    }
-    int h[C];  // Pillow's uint8 intermediate, kept in a register
 #pragma unroll
-    for (int c = 0; c < C; c++) h[c] = NONNEG ? (int)((unsigned)acc[c] >> 22) : clip8_int(acc[c]);
+      for (int c = 0; c < C; c++) h[c] = __float_as_int(accf[c]);
+    } else {
+      int acc[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) acc[c] = AA_V3_ABL == 5 ? (int)v[c] : 1 << 21;
+#pragma unroll
+      for (int j = 0; j < (AA_V3_ABL == 5 ? 0 : TW); j++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const int bi = j * C + c;
+          const int px = (int)((v[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
+          acc[c] += px * wreg[j];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < C; c++) h[c] = NONNEG ? (int)((unsigned)acc[c] >> 22) : clip8_int(acc[c]);
+    }
+    auto vmac = [&](int a, int hv, int w) -> int {  // one vertical tap
+      if constexpr (FLT) return __float_as_int(__int_as_float(a) + __int_as_float(hv) * __int_as_float(w));
+      else return a + __mul24(hv, w);
+    };
     // accumulator set k is output o_base+k; this row feeds outputs sc.first .. sc.first+MAXC-1 (zero weights beyond)
     const int idx0 = sc.first - o_base;  // 0 in steady state; negative while the band's first rows still feed
                                          // outputs that belong to the previous band
@@ -292,7 +322,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       for (int k = 0; k < MAXC; k++) {
         if (k >= 2 && sc.w[k] == 0) break;  // wave-uniform: most rows feed two outputs only
 #pragma unroll
-        for (int c = 0; c < C; c++) A[k][c] += __mul24(h[c], sc.w[k]);
+        for (int c = 0; c < C; c++) A[k][c] = vmac(A[k][c], h[c], sc.w[k]);
       }
     } else if (idx0 < 0 && idx0 > -MAXC) {
 #pragma unroll
@@ -301,7 +331,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
           for (int k = s; k < MAXC; k++)
 #pragma unroll
-            for (int c = 0; c < C; c++) A[k - s][c] += __mul24(h[c], sc.w[k]);
+            for (int c = 0; c < C; c++) A[k - s][c] = vmac(A[k - s][c], h[c], sc.w[k]);
         }
       }
     }
@@ -407,9 +437,9 @@ int pick_ybands(int64_t items_per_band, double slots, int taps_h, int64_t H, int
   return (int)ybands;
 }
 
-template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC>
+template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC, bool FLT = false>
 int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
-  auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC>;
+  auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC, FLT>;
   const int spb = p.strips_per_block;
   const int sgroups = (p.nstrips + spb - 1) / spb;
   const size_t lds_blk = lds * spb;
@@ -463,6 +493,26 @@ int launch(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, i
   return launch_g<C, TW, 8>(maxc, p, q, lds, grid);
 }
 
+// harness (float) arithmetic: the down-scaling window widths only, generic window addressing
+template <int C, int TW>
+int launch_flt(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
+  const bool two = p.nseg > 64;
+  if (maxc <= 2) return two ? launch_k<C, TW, 8, 2, true, false, false, true>(p, q, lds, grid)
+                            : launch_k<C, TW, 8, 2, false, false, false, true>(p, q, lds, grid);
+  if (maxc <= 3) return two ? launch_k<C, TW, 8, 3, true, false, false, true>(p, q, lds, grid)
+                            : launch_k<C, TW, 8, 3, false, false, false, true>(p, q, lds, grid);
+  return two ? launch_k<C, TW, 8, 4, true, false, false, true>(p, q, lds, grid)
+             : launch_k<C, TW, 8, 4, false, false, false, true>(p, q, lds, grid);
+}
+
+template <int C>
+int dispatch_tw_flt(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
+  if (tw <= 6) return launch_flt<C, 6>(maxc, p, q, lds, grid);
+  if (tw <= 8) return launch_flt<C, 8>(maxc, p, q, lds, grid);
+  if (tw <= 12) return launch_flt<C, 12>(maxc, p, q, lds, grid);
+  return 0;
+}
+
 template <int C>
 int dispatch_tw(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
 #ifdef AA_V3_HEADLINE_ONLY  // developer builds: one window width, so the file compiles in seconds
@@ -487,9 +537,11 @@ int round_tw(int taps) {
 
 int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   if (q.dtype != AA_U8) return 0;
-  if (q.ah.kind != AA_TABLE_PIL || q.aw.kind != AA_TABLE_PIL) return 0;
+  const bool flt = q.ah.kind == AA_TABLE_F32 && q.aw.kind == AA_TABLE_F32;  // the reference harness's uint8 semantics
+  if (!flt && (q.ah.kind != AA_TABLE_PIL || q.aw.kind != AA_TABLE_PIL)) return 0;
   // channels_last with 3 or 4 interleaved channels, or planar bytes: NCHW is N*C single-channel images
   const bool planar = q.layout == AA_NCHW || q.C == 1;
+  if (flt && planar) return 0;  // (harness mode is fused for interleaved channels only)
   const int C = planar ? 1 : (int)q.C;
   const int64_t NI = planar ? q.N * q.C : q.N;  // images the kernel sees
   if (C != 1 && C != 3 && C != 4) return 0;
@@ -497,7 +549,8 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   if (q.ah.scatter_off <= 0 || q.ah.scatter_max <= 0 || q.ah.scatter_max > 4) return 0;
   if (q.H < q.oH) return 0;  // down-scaling (or equal) in H: output rows complete one at a time, in order
   const int taps_w = q.aw.max_taps > 0 ? q.aw.max_taps : q.aw.ksize;
-  const int tw = round_tw(taps_w);
+  int tw = round_tw(taps_w);
+  if (flt && tw != 0 && tw < 6) tw = 6;  // the float variant is instantiated for windows of 6, 8 and 12 taps
   if (tw == 0 || q.W < tw) return 0;
   if ((q.oW * C) % 4 != 0 || (C == 3 && q.oW % 4 != 0)) return 0;
   if ((uint64_t)q.H * q.W * C > 0xFFFFFFF0ull || (uint64_t)q.oH * q.oW * C > 0xFFFFFFF0ull) return 0;
@@ -539,6 +592,11 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   const int64_t grid = 0;  // decided per kernel instantiation (launch_k)
   p.ybands = 1;
 
+  if (flt) {
+    const int rc = C == 3 ? dispatch_tw_flt<3>(tw, q.ah.scatter_max, p, q, lds, grid) : dispatch_tw_flt<4>(tw, q.ah.scatter_max, p, q, lds, grid);
+    if (rc == 1) *variant = "fused_u8_nhwc_harness_v3";
+    return rc;
+  }
   const int rc = C == 3   ? dispatch_tw<3>(tw, q.ah.scatter_max, p, q, lds, grid)
                  : C == 4 ? dispatch_tw<4>(tw, q.ah.scatter_max, p, q, lds, grid)
                           : dispatch_tw<1>(tw, q.ah.scatter_max, p, q, lds, grid);
