@@ -1,0 +1,555 @@
+// aa_fused_u8_v3_impl.h — fused resample for uint8 channels_last, Pillow arithmetic: wave-autonomous streaming.
+//
+// Third design, after measuring the first two on MI355X (DESIGN.md §Kernels has the numbers):
+//   v1 (aa_fused_u8.hip)     per-lane window loads from global memory -> TCP 95 % busy, 3.4 TB/s;
+//   v2 (aa_fused_u8_v2.hip)  LDS-DMA staging + producer/consumer waves + shared LDS ring -> the data-movement skeleton
+//                            alone (all arithmetic removed) takes 0.33 ms per 1024 images: LDS bound (window reads with
+//                            2-3-way bank conflicts + 3 byte-writes per pixel + ring reads), plus barrier coupling.
+// v3 keeps v2's clean global path and removes everything else that touched LDS:
+//   * ONE WAVE = ONE WORKGROUP = one 64-column strip of one band of one image.  No barriers, no shared ring, no
+//     consumer waves: waves are completely independent, so 32 of them fit a CU and hide each other's latency;
+//   * each wave streams its strip's input-row segments into a private G-slot LDS ring with one LDS-DMA instruction
+//     per row (`buffer_load_dwordx4 ... lds`, 16 B per lane, range-checked, zero address VALU), G-2 rows in flight;
+//   * horizontal pass: one lane per output pixel, dword-aligned LDS window reads + v_alignbyte, C*taps SDWA
+//     multiplies + add3 (as v2);
+//   * the VERTICAL PASS RUNS IN REGISTERS, in scatter form: the clipped uint8 result of input row r (C values per
+//     lane, never packed, never stored) is multiplied by the wave-uniform weights that row r has in the <=4 output
+//     rows still open (the table's scatter section, read with scalar loads one row ahead) and accumulated into
+//     per-lane accumulators: one v_mad_i32_i24 per tap-channel, no LDS, no extraction;
+//   * when an output row's last input row has been absorbed, its accumulators are clipped and packed
+//     (v_ashr_pk_u8_i32), the 3-byte pixels of each lane quad are merged into 3 dwords with one DPP move + one
+//     v_perm, and 48 of 64 lanes store one dword each: a 192-byte contiguous, fully coalesced row segment.
+// Integer arithmetic is associative, so accumulating taps in scatter order gives bit-identical Pillow results.
+
+//
+// This header holds the kernel template and its launch chain; it is compiled once per channel count
+// (aa_fused_u8_v3_c1.hip / _c3.hip / _c4.hip) so that the instantiations build in parallel, and the host-side
+// dispatcher lives in aa_fused_u8_v3.hip.
+#pragma once
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "aa_common.h"
+
+#ifndef AA_V3_ABL
+#define AA_V3_ABL 0  // developer ablations (wrong results!): 1 no stores, 2 no DMA waits, 4 no DMA at all,
+                     // 5 no horizontal MACs, 6 DMA only (no LDS reads, no arithmetic, no stores)
+#endif
+
+#ifndef AA_V3_AUX
+#define AA_V3_AUX 0  // cache-policy bits of the staging DMA (developer knob)
+#endif
+
+// (shared by the per-channel-count translation units and the host-side dispatcher)
+struct FusedU8V3Params {
+  int H, W, oH, oW;
+  int ksize_w, ksize_h;
+  int ybands, nstrips;
+  int strips_per_block;  // waves per workgroup
+  int strip_w;           // output columns per strip (<= 64, multiple of 4)
+  int nseg;        // 16-byte pieces per staged row segment (<= 128)
+  int seg_bytes;   // nseg * 16
+  int sc_off;      // scatter section of the H table (bytes from table start): one 8-int record per input row
+  int in_mis;      // (input pointer & 15): the kernel gets the pointer rounded down to 16 B
+  unsigned long long img_in_bytes, img_out_bytes, total_in_bytes, total_out_bytes;
+  long long n_images;  // = N for channels_last, N*C for planar input
+};
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+
+
+__device__ inline unsigned pack4_clip8(int a0, int a1, int a2, int a3) {  // semantics: see aa_fused_u8.hip
+  unsigned d;
+  asm("v_ashr_pk_u8_i32 %0, %1, %2, 22\n\tv_ashr_pk_u8_i32 %0, %3, %4, 22 op_sel:[0,0,0,1]"
+      : "=&v"(d)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+  return d;
+}
+
+__device__ inline int clip8_int(int acc) {  // Pillow clip8(ss >> 22) as a plain integer 0..255
+  acc >>= 22;
+  return acc < 0 ? 0 : (acc > 255 ? 255 : acc);
+}
+
+__device__ inline void wait_vmcnt(int n) {  // rounding n DOWN only waits longer
+  if (n >= 12) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); return; }
+  if (n >= 8) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); return; }
+  if (n >= 6) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); return; }
+  if (n >= 4) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); return; }
+  if (n >= 3) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); return; }
+  if (n >= 2) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); return; }
+  if (n >= 1) { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); return; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// G: staged rows per wave (even).  MAXC: outputs one input row can feed (= accumulator sets kept open).
+// NONNEG: no negative weights (triangle / box): the horizontal-pass sum cannot leave [0, 255.5], so Pillow's clip8 of the
+//         intermediate is a plain shift.  PERIODIC: G*row_bytes is a multiple of 16, so the 16-byte phase of a staged
+//         row depends only on its stage slot and the per-slot LDS window addresses are loop invariants.
+// FLT: the reference harness's uint8 semantics instead of Pillow's (AA_TABLE_F32 tables): bytes are converted to fp32,
+//      both passes run in fp32 with separately rounded product and sum in tap order (the intermediate is never rounded),
+//      the result is clamped to [0,255] and truncated (test.py:52-58,72,75).  Registers hold float bit patterns.
+template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC, bool FLT = false>
+__global__ void __launch_bounds__(512)
+fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const char *__restrict__ tab_w,
+                        const char *__restrict__ tab_h, const FusedU8V3Params p) {
+  constexpr int NV = (C * TW + 3) / 4;  // dwords holding one window
+  constexpr int ND = NV + 1;            // aligned dwords fetched per window
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+  // a workgroup is the nstrips_blk independent waves (strips) of one band: no barrier, no shared LDS; they only
+  // share a CU so that the 64-byte sectors two neighbouring segments have in common come from L1/L2, not HBM
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int b = blockIdx.x;
+  const int sgroups = (p.nstrips + p.strips_per_block - 1) / p.strips_per_block;
+  const int strip = (b % sgroups) * p.strips_per_block + wv;
+  b /= sgroups;
+  if (strip >= p.nstrips) return;
+  const int yb = b % p.ybands;
+  const int n = b / p.ybands;
+  const int ox0 = strip * p.strip_w;
+  const int bw = min(p.strip_w, p.oW - ox0);
+  const int oy0 = (int)((long long)yb * p.oH / p.ybands);
+  const int oy1 = (int)((long long)(yb + 1) * p.oH / p.ybands);
+
+  const int32_t *__restrict__ xmin_w = (const int32_t *)(tab_w + aa_table_xmin_off());
+  const int32_t *__restrict__ xsize_w = (const int32_t *)(tab_w + aa_table_xsize_off(p.oW));
+  const int32_t *__restrict__ kw = (const int32_t *)(tab_w + aa_table_w_off(p.oW));
+  const int32_t *__restrict__ ymin_h = (const int32_t *)(tab_h + aa_table_xmin_off());
+  const int32_t *__restrict__ ysize_h = (const int32_t *)(tab_h + aa_table_xsize_off(p.oH));
+  const int32_t *__restrict__ sc_rec = (const int32_t *)(tab_h + p.sc_off);
+
+  // input rows this band needs: [r_begin, r_stop)
+  const int r_begin = __builtin_amdgcn_readfirstlane(ymin_h[oy0]);
+  const int ylm = __builtin_amdgcn_readfirstlane(ymin_h[oy1 - 1]);
+  const int yls = __builtin_amdgcn_readfirstlane(ysize_h[oy1 - 1]);
+  const int r_stop = ylm + (yls > 1 ? yls : 1);
+  const int n_rows = r_stop - r_begin;
+  const int n_groups = (n_rows + G - 1) / G;
+
+  // ---- per-lane horizontal-pass state ------------------------------------------------------------------------
+  const bool active = lane < bw;
+  const int ox = ox0 + (active ? lane : 0);
+  const int xm = xmin_w[ox];
+  int xs = xsize_w[ox];
+  xs = xs > 1 ? xs : 1;
+  int lead = xm + TW - p.W;  // right-align windows whose zero-weight padding would leave the row
+  lead = lead > 0 ? lead : 0;
+  const int start = xm - lead;
+  int wreg[TW];
+#pragma unroll
+  for (int j = 0; j < TW; j++) {
+    const int src = j - lead;
+    int w = (src >= 0 && src < xs && src < p.ksize_w) ? kw[(size_t)ox * p.ksize_w + src] : 0;
+    wreg[j] = FLT ? w : (w << 8) >> 8;  // 24-bit operand for v_mul_i32_i24 (FLT: the float's bit pattern, 0 = +0.0f)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table loads done: from here on vmcnt counts DMAs and stores
+  const int seg_first = __builtin_amdgcn_readfirstlane(start * C);  // lane 0 is always active
+  const int c_l = start * C - seg_first;                            // window offset inside the segment (bytes)
+
+  const unsigned long long img_off = (unsigned long long)p.in_mis + (unsigned long long)n * p.img_in_bytes;
+  const unsigned long long base_off = img_off & ~15ull;
+  unsigned long long remaining = p.total_in_bytes - base_off;
+  remaining = (remaining + 3ull) & ~3ull;  // the range check works per dword: serve the last, partial one too
+  if (remaining > 0xFFFFFFFCull) remaining = 0xFFFFFFFCull;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(in + base_off), 0, (unsigned)remaining, 0x00020000);
+  const unsigned row_bytes = (unsigned)p.W * C;
+  const int lds_base = wv * G * p.seg_bytes;  // this wave's private stage ring
+  const unsigned lane_lds = (unsigned)(lds_base + c_l);
+  const bool dma_lane0 = lane < p.nseg;
+  const bool dma_lane1 = lane + 64 < p.nseg;
+  constexpr int dma_per_row = TWO_DMA ? 2 : 1;
+  const unsigned voff = (unsigned)lane * 16u;
+
+  // ---- output: range-checked view of this image's output, per-lane dword slot inside the strip's row segment ----
+  const unsigned long long out_off = (unsigned long long)n * p.img_out_bytes;
+  unsigned long long out_rem = p.total_out_bytes - out_off;
+  if (out_rem > 0xFFFFFFFFull) out_rem = 0xFFFFFFFFull;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(out + out_off), 0, (unsigned)out_rem, 0x00020000);
+  const unsigned out_row_bytes = (unsigned)p.oW * C;
+  unsigned store_voff;
+  bool store_lane;
+  unsigned perm_sel = 0;
+  if constexpr (C == 3) {
+    // a quad of lanes holds 4 pixels = 12 bytes = 3 dwords; quad lanes 0..2 each assemble and store one of them
+    const int q = lane & 3;
+    store_voff = (unsigned)(ox0 * 3 + (lane >> 2) * 12 + q * 4);
+    store_lane = (q != 3) && ((lane | 3) < bw);  // bw is a multiple of 4: the whole quad is in range or none of it
+    perm_sel = q == 0 ? 0x04020100u : (q == 1 ? 0x05040201u : 0x06050402u);
+  } else if constexpr (C == 1) {
+    // planar bytes: a quad of lanes holds 4 consecutive bytes = 1 dword, stored by the quad's first lane
+    store_voff = (unsigned)(ox0 + lane);
+    store_lane = ((lane & 3) == 0) && ((lane | 3) < bw);
+  } else {
+    store_voff = (unsigned)((ox0 + lane) * 4);
+    store_lane = active;
+  }
+
+  // a: byte offset (from the descriptor base) of the segment start of the CURRENT row
+  unsigned a = (unsigned)(img_off - base_off) + (unsigned)seg_first + (unsigned)r_begin * row_bytes;
+
+  // ---- vertical-pass state: MAXC accumulator sets, set k belongs to output row o_base + k --------------------------
+  int A[MAXC][C];
+#pragma unroll
+  for (int k = 0; k < MAXC; k++)
+#pragma unroll
+    for (int c = 0; c < C; c++) A[k][c] = FLT ? 0 : 1 << 21;
+  int o_base = oy0;
+
+  auto dma = [&](unsigned a_row, int slot) {
+    if (AA_V3_ABL == 4) return;
+    const unsigned soff = AA_V3_ABL == 7 ? (a_row & 0x3F0u) : (a_row & ~15u);  // 7: every DMA hits the same 1.6 KB
+    const int dst = lds_base + slot * p.seg_bytes;
+    if (dma_lane0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, soff, 0, AA_V3_AUX);
+    if constexpr (TWO_DMA) {
+      if (dma_lane1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst + 1024), 16, voff + 1024, soff, 0, AA_V3_AUX);
+    }
+  };
+  // per-slot loop invariants of the window reads (PERIODIC only): dword-aligned LDS address and 16-byte phase
+  unsigned slot_ra[G];
+  unsigned slot_ph[G];
+#pragma unroll
+  for (int j = 0; j < G; j++) {
+    const unsigned ph = (a + (unsigned)j * row_bytes) & 15u;
+    slot_ph[j] = (unsigned)(j * p.seg_bytes) + ph;  // uniform
+    slot_ra[j] = (lane_lds + slot_ph[j]) & ~3u;      // per lane
+  }
+  auto fetch = [&](unsigned a_row, int slot, unsigned (&d)[ND], bool tables = true) -> unsigned {
+    unsigned sa, ra;
+    if (AA_V3_ABL == 6) return 0;
+    if (PERIODIC && tables) {  // `slot` must be a compile-time constant here (register arrays)
+      sa = lane_lds + slot_ph[slot];  // only its low two bits are used (v_alignbyte)
+      ra = slot_ra[slot];
+    } else {
+      sa = lane_lds + (unsigned)(slot * p.seg_bytes) + (a_row & 15u);
+      ra = sa & ~3u;
+    }
+    const __attribute__((address_space(3))) unsigned *al = (const __attribute__((address_space(3))) unsigned *)(uintptr_t)ra;
+#pragma unroll
+    for (int k = 0; k < ND; k++) d[k] = al[k];
+    return sa;
+  };
+  // scatter record of an input row: first output it feeds, and its weight in that output and the next MAXC-1
+  struct Scatter { int first; int cc; int w[MAXC]; };  // raw record words (nothing depends on them until they are used)
+  auto load_scatter = [&](int r) -> Scatter {  // one 32-byte record: {first, count | completes << 16, w[6]}
+    Scatter s;                                   // (the section has H + 1 records: r == H reads the all-zero sentinel)
+    const int32_t *rec = (const int32_t *)((const char *)sc_rec + (unsigned)r * 32u);
+    s.first = __builtin_amdgcn_readfirstlane(rec[0]);
+    s.cc = __builtin_amdgcn_readfirstlane(rec[1]);  // count | completes << 16
+#pragma unroll
+    for (int k = 0; k < MAXC; k++) s.w[k] = __builtin_amdgcn_readfirstlane(rec[2 + k]);
+    return s;
+  };
+  auto trunc8 = [&](int bits) -> unsigned {  // harness: clamp to [0,255], truncating conversion (generic Store<uint8_t,float>)
+    float a = __int_as_float(bits);
+    a = a < 0.f ? 0.f : (a > 255.f ? 255.f : a);
+    return (unsigned)(int)a;
+  };
+  auto emit = [&](int oy) {  // accumulator set 0 is complete: clip, pack, merge quads, store; then slide the sets down
+    if constexpr (C == 3) {
+      const unsigned t = FLT ? (trunc8(A[0][0]) | (trunc8(A[0][1]) << 8) | (trunc8(A[0][2]) << 16))
+                             : pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][2]);
+      const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xF, 0xF, false);
+      const unsigned dw = __builtin_amdgcn_perm(nb, t, perm_sel);
+      if (store_lane && (AA_V3_ABL != 1 || dw == 0x12345678u))
+        __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+    } else if constexpr (C == 1) {
+      const unsigned t = pack4_clip8(A[0][0], A[0][0], A[0][0], A[0][0]);  // the lane's byte, replicated
+      const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x55 /*quad_perm:[1,1,1,1]*/, 0xF, 0xF, false);
+      const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xAA /*quad_perm:[2,2,2,2]*/, 0xF, 0xF, false);
+      const unsigned n3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xFF /*quad_perm:[3,3,3,3]*/, 0xF, 0xF, false);
+      const unsigned dw = (t & 0x000000ffu) | (n1 & 0x0000ff00u) | (n2 & 0x00ff0000u) | (n3 & 0xff000000u);
+      if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+    } else {
+      const unsigned dw = FLT ? (trunc8(A[0][0]) | (trunc8(A[0][1]) << 8) | (trunc8(A[0][2]) << 16) | (trunc8(A[0][C - 1]) << 24))
+                              : pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][C - 1]);
+      if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+    }
+#pragma unroll
+    for (int k = 0; k + 1 < MAXC; k++)
+#pragma unroll
+      for (int c = 0; c < C; c++) A[k][c] = A[k + 1][c];
+#pragma unroll
+    for (int c = 0; c < C; c++) A[MAXC - 1][c] = FLT ? 0 : 1 << 21;
+  };
+  // one input row: horizontal pass from the fetched window, then scatter into the open output rows
+  // the window of the CURRENT row, realigned; consumes the LDS reads issued one row earlier
+  auto realign = [&](const unsigned (&d)[ND], unsigned sa, unsigned (&v)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sa);
+  };
+  auto row_step = [&](const unsigned (&v)[NV], const Scatter &sc) {
+    if (AA_V3_ABL == 6) return;
+    int h[C];  // the horizontal-pass result of this row: Pillow's uint8 intermediate, or (FLT) the float's bits
+    if constexpr (FLT) {
+      float accf[C];
+#pragma unroll
+      for (int j = 0; j < TW; j++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const int bi = j * C + c;
+          const float px = (float)((v[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
+          const float prod = px * __int_as_float(wreg[j]);  // taps outside the window have weight +0.0: adding their
+          accf[c] = j == 0 ? prod : accf[c] + prod;          // products never changes a value (bytes are finite)
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < C; c++) h[c] = __float_as_int(accf[c]);
+    } else {
+      int acc[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) acc[c] = AA_V3_ABL == 5 ? (int)v[c] : 1 << 21;
+#pragma unroll
+      for (int j = 0; j < (AA_V3_ABL == 5 ? 0 : TW); j++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          const int bi = j * C + c;
+          const int px = (int)((v[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
+          acc[c] += px * wreg[j];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < C; c++) h[c] = NONNEG ? (int)((unsigned)acc[c] >> 22) : clip8_int(acc[c]);
+    }
+    auto vmac = [&](int a, int hv, int w) -> int {  // one vertical tap
+      if constexpr (FLT) return __float_as_int(__int_as_float(a) + __int_as_float(hv) * __int_as_float(w));
+      else return a + __mul24(hv, w);
+    };
+    // accumulator set k is output o_base+k; this row feeds outputs sc.first .. sc.first+MAXC-1 (zero weights beyond)
+    const int idx0 = sc.first - o_base;  // 0 in steady state; negative while the band's first rows still feed
+                                         // outputs that belong to the previous band
+    if (__builtin_expect(idx0 == 0, 1)) {
+#pragma unroll
+      for (int k = 0; k < MAXC; k++) {
+        if (k >= 2 && sc.w[k] == 0) break;  // wave-uniform: most rows feed two outputs only
+#pragma unroll
+        for (int c = 0; c < C; c++) A[k][c] = vmac(A[k][c], h[c], sc.w[k]);
+      }
+    } else if (idx0 < 0 && idx0 > -MAXC) {
+#pragma unroll
+      for (int s = 1; s < MAXC; s++) {
+        if (idx0 == -s) {
+#pragma unroll
+          for (int k = s; k < MAXC; k++)
+#pragma unroll
+            for (int c = 0; c < C; c++) A[k - s][c] = vmac(A[k - s][c], h[c], sc.w[k]);
+        }
+      }
+    }
+    const int sc_end = sc.first + (sc.cc >> 16);     // outputs [first, sc_end) take their LAST row here
+    const int e_end = sc_end < oy1 ? sc_end : oy1;  // (outputs below o_base belong to the previous band)
+    while (o_base < e_end) {
+      emit(o_base);
+      o_base++;
+    }
+  };
+
+  // prologue: the first G rows in flight, window reads of row 0 issued
+  for (int i = 0; i < G; i++)
+    if (i < n_rows) dma(a + (unsigned)i * row_bytes, i);
+  unsigned d0[ND], d1[ND];
+  unsigned sa0 = 0, sa1 = 0;
+  Scatter sc0 = load_scatter(r_begin), sc1 = sc0;
+  {
+    const int younger = (n_rows < G ? n_rows : G) - 1;
+    wait_vmcnt(younger * dma_per_row);
+    sa0 = fetch(a, 0, d0, false);
+  }
+  // Invariant at the top of row x (slot x % G): DMAs issued up to row x+G-1; row x's window reads issued into d0 (x
+  // even) / d1 (x odd); its scatter record loaded into sc0 / sc1.  Output stores also count in vmcnt: they are
+  // younger than every DMA the wait below must cover, so "at most G-2 outstanding" still implies row x+1 has landed
+  // (it only waits for a few more rows than strictly necessary).
+  int r = r_begin;
+  for (int g = 0; g < n_groups; g++) {
+    const int x0 = g * G;
+    if (x0 + 2 * G <= n_rows) {  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
+#pragma unroll
+      for (int i = 0; i < G; i++) {
+        if (AA_V3_ABL != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_row * (G - 2)) : "memory");
+        // Order matters for the lgkm counter (LDS and scalar loads share it and scalar loads return out of order,
+        // so every wait is lgkmcnt(0)): first consume the reads issued a whole row ago (no stall), THEN issue the
+        // next row's window reads and scatter record, which land while this row's ~45 VALU instructions run.
+        unsigned v[NV];
+        if ((i & 1) == 0) {
+          realign(d0, sa0, v);
+          __builtin_amdgcn_sched_barrier(0);
+          sc1 = load_scatter(r + 1);
+          sa1 = fetch(a + row_bytes, (i + 1) % G, d1);
+          __builtin_amdgcn_sched_barrier(0);
+          row_step(v, sc0);
+        } else {
+          realign(d1, sa1, v);
+          __builtin_amdgcn_sched_barrier(0);
+          sc0 = load_scatter(r + 1);
+          sa0 = fetch(a + row_bytes, (i + 1) % G, d0);
+          __builtin_amdgcn_sched_barrier(0);
+          row_step(v, sc1);
+        }
+        dma(a + (unsigned)G * row_bytes, i);  // the slot just consumed gets row x+G
+        a += row_bytes;
+        r++;
+        __builtin_amdgcn_sched_barrier(0);  // keep the unrolled rows from interleaving: it only costs registers
+      }
+    } else {
+      for (int i = 0; i < G; i++) {
+        const int x = x0 + i;
+        if (x >= n_rows) break;
+        if (x + 1 < n_rows) {
+          int younger = n_rows - 1 - (x + 1);
+          younger = younger < G - 2 ? younger : G - 2;
+          wait_vmcnt(younger * dma_per_row);
+          if ((i & 1) == 0) { sc1 = load_scatter(r + 1); sa1 = fetch(a + row_bytes, (i + 1) % G, d1, false); }
+          else { sc0 = load_scatter(r + 1); sa0 = fetch(a + row_bytes, (i + 1) % G, d0, false); }
+        }
+        unsigned v[NV];
+        if ((i & 1) == 0) { realign(d0, sa0, v); row_step(v, sc0); }
+        else { realign(d1, sa1, v); row_step(v, sc1); }
+        if (x + G < n_rows) dma(a + (unsigned)G * row_bytes, i);
+        a += row_bytes;
+        r++;
+      }
+    }
+  }
+}
+
+// staged rows per wave: 8; developer builds (-DAA_V2_TUNING) read AA_V3_G
+inline int aa_v3_group() {
+#ifdef AA_V2_TUNING
+  if (const char *e = getenv("AA_V3_G")) return atoi(e);
+#endif
+  return 8;
+}
+
+// Row bands: every extra band re-reads and re-filters ~taps_h halo rows, but the grid must fill the chip's resident
+// wave slots a near-integer number of times or the last partial round idles most CUs.  Pick the band count
+// minimising (1 + halo fraction) / round efficiency.
+int pick_ybands(int64_t items_per_band, double slots, int taps_h, int64_t H, int64_t oH) {
+  const int64_t max_yb = oH / 8 > 1 ? oH / 8 : 1;
+  int64_t ybands = 1;
+  double best = 1e30;
+  for (int64_t yb = 1; yb <= max_yb && yb <= 64; yb++) {
+    const double rounds = (double)items_per_band * yb / slots;
+    const double eff = rounds / ceil(rounds);
+    const double halo = 1.0 + (double)(yb - 1) * taps_h / (double)H;
+    const double cost = halo / eff;
+    if (cost < best - 1e-9) {
+      best = cost;
+      ybands = yb;
+    }
+  }
+  if (const char *e = getenv("AA_FUSED_YBANDS")) {  // experiment knob
+    const int64_t v = atoll(e);
+    if (v >= 1 && v <= max_yb) ybands = v;
+  }
+  return (int)ybands;
+}
+
+template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC, bool FLT = false>
+int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
+  auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC, FLT>;
+  const int spb = p.strips_per_block;
+  const int sgroups = (p.nstrips + spb - 1) / spb;
+  const size_t lds_blk = lds * spb;
+  static int blocks_per_cu[9] = {0};  // resident workgroups per CU for this instantiation, by waves per workgroup
+  if (blocks_per_cu[spb] == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * spb, lds_blk) != hipSuccess || nb <= 0) nb = 16 / spb;
+    blocks_per_cu[spb] = nb < 1 ? 1 : nb;
+  }
+  const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
+  p.ybands = pick_ybands(p.n_images * sgroups, (double)aa_device_cu_count() * blocks_per_cu[spb], taps_h, q.H, q.oH);
+  const int64_t grid = p.n_images * (int64_t)p.ybands * sgroups;
+  if (grid > 0x7FFFFFFF) return 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk,
+                     q.stream, (const uint8_t *)q.in - p.in_mis, (uint8_t *)q.out, (const char *)q.aw.table_dev,
+                     (const char *)q.ah.table_dev, p);
+  AA_HIP_CHECK_LAUNCH();
+  return 1;
+}
+
+template <int C, int TW, int G, int MAXC>
+int launch_gm(const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
+  const bool nonneg = q.aw.filter != AA_FILTER_CUBIC && q.ah.filter != AA_FILTER_CUBIC;
+  const bool periodic = ((unsigned long long)G * (unsigned long long)p.W * C) % 16 == 0;
+  if (p.nseg > 64) {  // wide segments (large down-scales): the generic-address variant only
+    return nonneg ? launch_k<C, TW, G, MAXC, true, true, false>(p, q, lds, grid)
+                  : launch_k<C, TW, G, MAXC, true, false, false>(p, q, lds, grid);
+  }
+  if (nonneg) return periodic ? launch_k<C, TW, G, MAXC, false, true, true>(p, q, lds, grid)
+                              : launch_k<C, TW, G, MAXC, false, true, false>(p, q, lds, grid);
+  return periodic ? launch_k<C, TW, G, MAXC, false, false, true>(p, q, lds, grid)
+                  : launch_k<C, TW, G, MAXC, false, false, false>(p, q, lds, grid);
+}
+
+template <int C, int TW, int G>
+int launch_g(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
+  if (maxc <= 2) return launch_gm<C, TW, G, 2>(p, q, lds, grid);
+  if (maxc <= 3) return launch_gm<C, TW, G, 3>(p, q, lds, grid);
+  return launch_gm<C, TW, G, 4>(p, q, lds, grid);
+}
+
+template <int C, int TW>
+int launch(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
+#ifdef AA_V2_TUNING
+  if (aa_v3_group() == 4) return launch_g<C, TW, 4>(maxc, p, q, lds, grid);
+  if (aa_v3_group() == 6) return launch_g<C, TW, 6>(maxc, p, q, lds, grid);
+  if (aa_v3_group() == 10) return launch_g<C, TW, 10>(maxc, p, q, lds, grid);
+  if (aa_v3_group() == 12) return launch_g<C, TW, 12>(maxc, p, q, lds, grid);
+  if (aa_v3_group() == 16) return launch_g<C, TW, 16>(maxc, p, q, lds, grid);
+#endif
+  return launch_g<C, TW, 8>(maxc, p, q, lds, grid);
+}
+
+// harness (float) arithmetic: the down-scaling window widths only, generic window addressing
+template <int C, int TW>
+int launch_flt(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
+  const bool two = p.nseg > 64;
+  if (maxc <= 2) return two ? launch_k<C, TW, 8, 2, true, false, false, true>(p, q, lds, grid)
+                            : launch_k<C, TW, 8, 2, false, false, false, true>(p, q, lds, grid);
+  if (maxc <= 3) return two ? launch_k<C, TW, 8, 3, true, false, false, true>(p, q, lds, grid)
+                            : launch_k<C, TW, 8, 3, false, false, false, true>(p, q, lds, grid);
+  return two ? launch_k<C, TW, 8, 4, true, false, false, true>(p, q, lds, grid)
+             : launch_k<C, TW, 8, 4, false, false, false, true>(p, q, lds, grid);
+}
+
+template <int C>
+int dispatch_tw_flt(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
+  if (tw <= 6) return launch_flt<C, 6>(maxc, p, q, lds, grid);
+  if (tw <= 8) return launch_flt<C, 8>(maxc, p, q, lds, grid);
+  if (tw <= 12) return launch_flt<C, 12>(maxc, p, q, lds, grid);
+  return 0;
+}
+
+template <int C>
+int dispatch_tw(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
+#ifdef AA_V3_HEADLINE_ONLY  // developer builds: one window width, so the file compiles in seconds
+  return tw == 6 ? launch<C, 6>(maxc, p, q, lds, grid) : 0;
+#endif
+  if (tw <= 2) return launch<C, 2>(maxc, p, q, lds, grid);
+  if (tw <= 4) return launch<C, 4>(maxc, p, q, lds, grid);
+  if (tw <= 6) return launch<C, 6>(maxc, p, q, lds, grid);
+  if (tw <= 8) return launch<C, 8>(maxc, p, q, lds, grid);
+  if (tw <= 12) return launch<C, 12>(maxc, p, q, lds, grid);
+  return 0;
+}
+
+int round_tw(int taps) {
+  const int opts[] = {2, 4, 6, 8, 12};
+  for (int o : opts)
+    if (taps <= o) return o;
+  return 0;
+}
+
+}  // namespace
+
+// per-channel-count entry points (one translation unit each)
+int aa_v3_launch_c1(int tw, int maxc, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c3(int tw, int maxc, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c4(int tw, int maxc, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
