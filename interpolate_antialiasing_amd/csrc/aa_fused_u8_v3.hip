@@ -9,7 +9,6 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   if (!flt && (q.ah.kind != AA_TABLE_PIL || q.aw.kind != AA_TABLE_PIL)) return 0;
   // channels_last with 3 or 4 interleaved channels, or planar bytes: NCHW is N*C single-channel images
   const bool planar = q.layout == AA_NCHW || q.C == 1;
-  if (flt && planar) return 0;  // (harness mode is fused for interleaved channels only)
   const int C = planar ? 1 : (int)q.C;
   const int64_t NI = planar ? q.N * q.C : q.N;  // images the kernel sees
   if (C != 1 && C != 3 && C != 4) return 0;
@@ -59,6 +58,7 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   const int rc = C == 3   ? aa_v3_launch_c3(tw, q.ah.scatter_max, flt, p, q, lds)
                  : C == 4 ? aa_v3_launch_c4(tw, q.ah.scatter_max, flt, p, q, lds)
                           : aa_v3_launch_c1(tw, q.ah.scatter_max, flt, p, q, lds);
-  if (rc == 1) *variant = flt ? "fused_u8_nhwc_harness_v3" : (planar ? "fused_u8_planar_pil_v3" : "fused_u8_nhwc_pil_v3");
+  if (rc == 1) *variant = flt ? (planar ? "fused_u8_planar_harness_v3" : "fused_u8_nhwc_harness_v3")
+                        : (planar ? "fused_u8_planar_pil_v3" : "fused_u8_nhwc_pil_v3");
   return rc;
 }

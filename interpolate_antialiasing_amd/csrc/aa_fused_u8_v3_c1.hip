@@ -2,6 +2,5 @@
 #include "aa_fused_u8_v3_impl.h"
 
 int aa_v3_launch_c1(int tw, int maxc, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
-  if (flt) return 0;  // the float (harness) mode is instantiated for interleaved channels only
-  return dispatch_tw<1>(tw, maxc, p, q, lds, 0);
+  return flt ? dispatch_tw_flt<1>(tw, maxc, p, q, lds, 0) : dispatch_tw<1>(tw, maxc, p, q, lds, 0);
 }

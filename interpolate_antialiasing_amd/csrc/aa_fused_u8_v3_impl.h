@@ -261,7 +261,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       if (store_lane && (AA_V3_ABL != 1 || dw == 0x12345678u))
         __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
     } else if constexpr (C == 1) {
-      const unsigned t = pack4_clip8(A[0][0], A[0][0], A[0][0], A[0][0]);  // the lane's byte, replicated
+      const unsigned t = FLT ? trunc8(A[0][0]) * 0x01010101u : pack4_clip8(A[0][0], A[0][0], A[0][0], A[0][0]);  // the lane's byte, replicated
       const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x55 /*quad_perm:[1,1,1,1]*/, 0xF, 0xF, false);
       const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xAA /*quad_perm:[2,2,2,2]*/, 0xF, 0xF, false);
       const unsigned n3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xFF /*quad_perm:[3,3,3,3]*/, 0xF, 0xF, false);

@@ -342,7 +342,8 @@ def test_fused_kernels_match_generic_at_full_size(aa):
     harness = lambda fn: (lambda x, size: fn(x, size, uint8_mode="harness"))                             # reference harness semantics
     cases += [(harness(aa.linear_forward), x8, [196, 320]), (harness(aa.cubic_forward), x8[:8], [196, 320]),
               (harness(aa.nearest_forward), x8[:8], [196, 320]), (harness(aa.linear_forward), x8t[:4], [320, 196]),
-              (harness(aa.cubic_forward), x4, [150, 252]), (harness(aa.linear_forward), x8[:2], [438, 320])]
+              (harness(aa.cubic_forward), x4, [150, 252]), (harness(aa.linear_forward), x8[:2], [438, 320]),
+              (harness(aa.linear_forward), x8p[:4], [196, 320]), (harness(aa.cubic_forward), x8p[:2], [196, 320])]  # test.py's layout
     xf = torch.rand(6, 3, 438, 906, device="cuda") * 255
     cases += [(aa.linear_forward, xf, [196, 320]), (aa.cubic_forward, xf, [196, 320]), (aa.nearest_forward, xf, [196, 320])]
     xc = torch.rand(3, 3, 1024, 1024, device="cuda") * 255                                              # config 2 shape
@@ -368,7 +369,7 @@ def test_fused_kernels_match_generic_at_full_size(aa):
             assert torch.equal(y1, y0), (getattr(fn, "__name__", "backward"), tuple(x.shape), size)
     finally:
         _lib.set_fused(1)
-    assert {"fused_u8_nhwc_pil_v3", "fused_u8_planar_pil_v3", "fused_u8_nhwc_harness_v3", "fused_f32_nchw",
+    assert {"fused_u8_nhwc_pil_v3", "fused_u8_planar_pil_v3", "fused_u8_nhwc_harness_v3", "fused_u8_planar_harness_v3", "fused_f32_nchw",
             "fused_f32_nchw_up"} <= fused_seen, fused_seen
 
 
