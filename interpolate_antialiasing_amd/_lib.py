@@ -120,8 +120,13 @@ def check(rc: int, what: str = "") -> None:
         raise AAInterpError(msg)
 
 
+fused_epoch = 0  # bumped by set_fused: host-side plans that cached a workspace size are keyed on it
+
+
 def set_fused(enabled: int) -> int:
     """Enable/disable the fused kernels (process-wide); returns the previous setting."""
+    global fused_epoch
+    fused_epoch += 1
     return int(load().aa_set_fused(int(enabled)))
 
 

@@ -37,6 +37,7 @@ __all__ = ["linear_forward", "nearest_forward", "cubic_forward", "linear_backwar
            "get_uint8_mode", "last_variant"]
 
 _uint8_mode = "pil"
+_plans = {}  # per call shape: (axis descriptors, workspace bytes); see _forward
 
 _DTYPE_IDS = {torch.uint8: _lib.U8, torch.float32: _lib.F32, torch.float64: _lib.F64, torch.float16: _lib.F16,
               torch.bfloat16: _lib.BF16}
@@ -136,16 +137,30 @@ def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequen
     out = torch.empty((n, c, oh, ow), dtype=x.dtype, device=dev, memory_format=mf)
     if n == 0:
         return out
-    with torch.cuda.device(dev):
-        th = tables.get_table(filter_id, kind, h, oh, align_corners, sh, dev)
-        tw = tables.get_table(filter_id, kind, w, ow, align_corners, sw, dev)
-        ah, aw = th.axis(), tw.axis()
-        dt = _DTYPE_IDS[x.dtype]
-        ws_bytes = L.aa_workspace_bytes(dt, layout, n, c, h, w, oh, ow, ctypes.byref(ah), ctypes.byref(aw))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        rc = L.aa_resample_fwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                               ctypes.c_void_p(ws.data_ptr() if ws is not None else 0), ws_bytes, dt, layout,
-                               n, c, h, w, ctypes.byref(ah), ctypes.byref(aw), tables._stream_ptr(dev))
+    dt = _DTYPE_IDS[x.dtype]
+    # host-side plan: the two cached tables' axis descriptors and the workspace size for this exact call shape
+    key = (filter_id, dt, layout, n, c, h, w, oh, ow, bool(align_corners), kind, sh, sw, dev.index, _lib.fused_epoch)
+    plan = _plans.get(key)
+    cur = torch.cuda.current_device()
+    if plan is None:
+        with torch.cuda.device(dev):
+            th = tables.get_table(filter_id, kind, h, oh, align_corners, sh, dev)
+            tw = tables.get_table(filter_id, kind, w, ow, align_corners, sw, dev)
+            ah, aw = th.axis(), tw.axis()
+            ws_bytes = L.aa_workspace_bytes(dt, layout, n, c, h, w, oh, ow, ctypes.byref(ah), ctypes.byref(aw))
+        plan = (ah, aw, ws_bytes, ctypes.byref(ah), ctypes.byref(aw), th, tw)  # (th, tw keep the device buffers alive)
+        if len(_plans) > 4096:
+            _plans.clear()
+        _plans[key] = plan
+    ah, aw, ws_bytes, pah, paw = plan[:5]
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    if dev.index == cur:
+        rc = L.aa_resample_fwd(x.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, dt, layout,
+                               n, c, h, w, pah, paw, torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        with torch.cuda.device(dev):
+            rc = L.aa_resample_fwd(x.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, dt,
+                                   layout, n, c, h, w, pah, paw, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, name)
     return out
 
