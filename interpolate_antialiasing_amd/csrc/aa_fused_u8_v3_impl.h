@@ -328,7 +328,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     if (__builtin_expect(idx0 == 0, 1)) {
 #pragma unroll
       for (int k = 0; k < MAXC; k++) {
-        if (k >= 2 && sc.w[k] == 0) break;  // wave-uniform: most rows feed two outputs only
+        if (k >= 2 && k >= (sc.cc & 0xFFFF)) break;  // wave-uniform: most rows feed two outputs only (a zero weight in
+                                                     // the MIDDLE of the range must not end the loop: test the count)
 #pragma unroll
         for (int c = 0; c < C; c++) A[k][c] = vmac(A[k][c], h[c], sc.w[k]);
       }
