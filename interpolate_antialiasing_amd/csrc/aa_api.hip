@@ -197,6 +197,7 @@ size_t aa_workspace_bytes(int dtype, int layout, int64_t N, int64_t C, int64_t H
   (void)oH;
   if (!ax_h || !ax_w || N <= 0) return 0;
   if (g_fused_enabled) {
+    if (g_fused_enabled == 1 && aa_fused_u8_v3_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
     if (aa_fused_u8_nhwc_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
     if (aa_fused_float_nchw_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
     if (aa_fused_float_nchw_up_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;

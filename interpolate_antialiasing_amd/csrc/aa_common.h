@@ -77,6 +77,7 @@ int aa_try_fused_u8_nhwc(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw_up(const AAProblem &p, const char **variant);  // H <= oH: adjoint (gather form), up-scaling
 int aa_try_fused_u8_nhwc_v3(const AAProblem &p, const char **variant);  // LDS-DMA staged, wave-autonomous, V pass in registers
+bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);

@@ -3,24 +3,46 @@
 
 #include "aa_fused_u8_v3_impl.h"
 
-int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
-  if (q.dtype != AA_U8) return 0;
-  const bool flt = q.ah.kind == AA_TABLE_F32 && q.aw.kind == AA_TABLE_F32;  // the reference harness's uint8 semantics
-  if (!flt && (q.ah.kind != AA_TABLE_PIL || q.aw.kind != AA_TABLE_PIL)) return 0;
+// Everything the kernel needs that can be known without the pointers (aa_workspace_bytes asks before they exist).
+static bool v3_shape_ok(int dtype, int layout, int64_t Cin, int64_t H, int64_t W, const aa_axis &ah, const aa_axis &aw, bool *flt_out,
+                        bool *planar_out, int *tw_out) {
+  if (dtype != AA_U8) return false;
+  const bool flt = ah.kind == AA_TABLE_F32 && aw.kind == AA_TABLE_F32;  // the reference harness's uint8 semantics
+  if (!flt && (ah.kind != AA_TABLE_PIL || aw.kind != AA_TABLE_PIL)) return false;
   // channels_last with 3 or 4 interleaved channels, or planar bytes: NCHW is N*C single-channel images
-  const bool planar = q.layout == AA_NCHW || q.C == 1;
-  const int C = planar ? 1 : (int)q.C;
-  const int64_t NI = planar ? q.N * q.C : q.N;  // images the kernel sees
-  if (C != 1 && C != 3 && C != 4) return 0;
+  const bool planar = layout == AA_NCHW || Cin == 1;
+  const int C = planar ? 1 : (int)Cin;
+  if (C != 1 && C != 3 && C != 4) return false;
+  const int64_t oH = ah.out_size, oW = aw.out_size;
   // the in-register vertical pass needs the H table's scatter section and at most 4 open output rows
-  if (q.ah.scatter_off <= 0 || q.ah.scatter_max <= 0 || q.ah.scatter_max > 4) return 0;
-  if (q.H < q.oH) return 0;  // down-scaling (or equal) in H: output rows complete one at a time, in order
-  const int taps_w = q.aw.max_taps > 0 ? q.aw.max_taps : q.aw.ksize;
+  if (ah.scatter_off <= 0 || ah.scatter_max <= 0 || ah.scatter_max > 4) return false;
+  if (H < oH) return false;  // down-scaling (or equal) in H: output rows complete one at a time, in order
+  const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
   int tw = round_tw(taps_w);
   if (flt && tw != 0 && tw < 6) tw = 6;  // the float variant is instantiated for windows of 6, 8 and 12 taps
-  if (tw == 0 || q.W < tw) return 0;
-  if ((q.oW * C) % 4 != 0 || (C == 3 && q.oW % 4 != 0)) return 0;
-  if ((uint64_t)q.H * q.W * C > 0xFFFFFFF0ull || (uint64_t)q.oH * q.oW * C > 0xFFFFFFF0ull) return 0;
+  if (tw == 0 || W < tw) return false;
+  if ((oW * C) % 4 != 0 || (C == 3 && oW % 4 != 0)) return false;
+  if ((uint64_t)H * W * C > 0xFFFFFFF0ull || (uint64_t)oH * oW * C > 0xFFFFFFF0ull) return false;
+  const double scale_w = (double)W / (double)oW;
+  const int span_px = (int)floor(63.0 * (scale_w > 0 ? scale_w : 0)) + 1 + tw;
+  const int nseg = (span_px * C + 3 + 15 + 15) / 16;
+  if (nseg > 128 || (size_t)aa_v3_group() * nseg * 16 > 64 * 1024) return false;
+  *flt_out = flt; *planar_out = planar; *tw_out = tw;
+  return true;
+}
+
+bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw) {
+  bool flt, planar;
+  int tw;
+  return ah && aw && v3_shape_ok(dtype, layout, C, H, W, *ah, *aw, &flt, &planar, &tw);
+}
+
+int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
+  bool flt, planar;
+  int tw;
+  if (!v3_shape_ok(q.dtype, q.layout, q.C, q.H, q.W, q.ah, q.aw, &flt, &planar, &tw)) return 0;
+  const int C = planar ? 1 : (int)q.C;
+  const int64_t NI = planar ? q.N * q.C : q.N;  // images the kernel sees
   if (((uintptr_t)q.out & 3) != 0) return 0;
   const int G = aa_v3_group();
 
