@@ -119,8 +119,8 @@ def secondary_configs(dev):
     round's BENCH json carries them: algorithmic GB/s = (input + output bytes) / event time.  Not the headline metric."""
     from interpolate_antialiasing_amd import _lib, extension_interpolate as aa
 
-    def timed(fn, reps=10):
-        for _ in range(3):
+    def timed(fn, reps=30):
+        for _ in range(10):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -187,8 +187,11 @@ def secondary_configs(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm-seconds", type=float, default=0.3,
+                    help="untimed spin-up before the W warm-up steps: the GPU needs ~20 ms of work to reach its sustained clock "
+                         "(a 5-step warm-up under-reports the steady state by 8 %%, see DESIGN.md section 5)")
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -223,6 +226,11 @@ def main():
     def step():
         return aa.linear_forward(x, [H_OUT, W_OUT], False)
 
+    t_spin = time.perf_counter() + max(0.0, args.prewarm_seconds)  # clock ramp: untimed, same work as a step
+    while time.perf_counter() < t_spin:
+        for _ in range(20):
+            y = step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         y = step()
     variant = _lib.last_variant()
@@ -265,7 +273,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"uint8 channels_last [{B},3,438,906]->[196,320] bilinear antialias per GPU "
                                    f"(BASELINE configs[1] batched), Pillow-exact integer arithmetic",
-                       "batch_per_gpu": B, "global_batch": B * world, "variant": variant,
+                       "batch_per_gpu": B, "global_batch": B * world, "variant": variant, "prewarm_s": args.prewarm_seconds,
                        "parallelism": f"batch-shard x{world}"},
             "max_abs_err_vs_oracle": max_abs_e,
             "images_per_s": round(total_images / wall, 1),

@@ -34,7 +34,8 @@
 
 #ifndef AA_V3_ABL
 #define AA_V3_ABL 0  // developer ablations (wrong results!): 1 no stores, 2 no DMA waits, 4 no DMA at all,
-                     // 5 no horizontal MACs, 6 DMA only (no LDS reads, no arithmetic, no stores)
+                     // 5 no horizontal MACs, 6 DMA only (no LDS reads, no arithmetic, no stores),
+                     // 7 DMAs that always hit cache, 9 every output row stored over row 0 (stores that stay in cache)
 #endif
 
 #ifndef AA_V3_AUX
@@ -259,7 +260,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xF, 0xF, false);
       const unsigned dw = __builtin_amdgcn_perm(nb, t, perm_sel);
       if (store_lane && (AA_V3_ABL != 1 || dw == 0x12345678u))
-        __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, AA_V3_ABL == 9 ? 0u : (unsigned)oy * out_row_bytes, 0);
     } else if constexpr (C == 1) {
       const unsigned t = FLT ? trunc8(A[0][0]) * 0x01010101u : pack4_clip8(A[0][0], A[0][0], A[0][0], A[0][0]);  // the lane's byte, replicated
       const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x55 /*quad_perm:[1,1,1,1]*/, 0xF, 0xF, false);
@@ -371,6 +372,10 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   for (int g = 0; g < n_groups; g++) {
     const int x0 = g * G;
     if (x0 + 2 * G <= n_rows) {  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
+      // Not a data dependence: once per G rows the strips of a band line up, so that the 192-byte pieces they store into
+      // the same output rows reach L2 within a few microseconds of each other and leave it as whole lines (measured
+      // -2 %; every strip of the workgroup runs the same number of groups, finished waves do not count).
+      __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int i = 0; i < G; i++) {
         if (AA_V3_ABL != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_row * (G - 2)) : "memory");
