@@ -262,16 +262,22 @@ int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int64_t H, i
 template <int TW, int G, bool TWO, int MAXC>
 int launch_k(FusedF32Params p, const AAProblem &q, size_t lds) {
   auto kern = fused_f32_nchw_kernel<TW, G, TWO, MAXC>;
-  const int spb = p.strips_per_block;
+  static int blocks_per_cu[9] = {0};
+  auto resident = [&](int s) {  // workgroups of s strips a CU holds
+    if (blocks_per_cu[s] == 0) {
+      int nb = 0;
+      if (lds * s > 64 * 1024 || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * s, lds * s) != hipSuccess || nb <= 0) nb = -1;
+      blocks_per_cu[s] = nb;
+    }
+    return blocks_per_cu[s];
+  };
+  // strips of a band share a workgroup unless single-strip workgroups put more waves on a CU (see aa_fused_u8_v3_impl.h)
+  int spb = p.strips_per_block;
+  if (spb > 1 && resident(1) > 0 && (resident(spb) < 0 || resident(1) > resident(spb) * spb)) spb = 1;
+  if (resident(spb) < 0) return 0;
+  p.strips_per_block = spb;
   const int sgroups = (p.nstrips + spb - 1) / spb;
   const size_t lds_blk = lds * spb;
-  if (lds_blk > 64 * 1024) return 0;
-  static int blocks_per_cu[9] = {0};
-  if (blocks_per_cu[spb] == 0) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * spb, lds_blk) != hipSuccess || nb <= 0) nb = 1;
-    blocks_per_cu[spb] = nb;
-  }
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   const int64_t planes = q.N * q.C;
   p.ybands = pick_ybands_f(planes * sgroups, (double)aa_device_cu_count() * blocks_per_cu[spb], taps_h, q.H, q.oH);
