@@ -107,13 +107,18 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   // share a CU so that the 64-byte sectors two neighbouring segments have in common come from L1/L2, not HBM
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int b = blockIdx.x;
+  // XCD-aware index mapping: the dispatcher deals consecutive workgroup ids round-robin to the chip's 8 XCDs, each with
+  // its own L2.  Workgroup id b = 8 * k + xcd; within an XCD, consecutive k walk the strips of one (image, band) group
+  // first, so that neighbouring strips (which share input sectors and output lines) meet in the SAME L2 at about the
+  // same time.  The grid is padded to whole rounds of 8 groups; the surplus workgroups exit here.
   const int sgroups = (p.nstrips + p.strips_per_block - 1) / p.strips_per_block;
-  const int strip = (b % sgroups) * p.strips_per_block + wv;
-  b /= sgroups;
+  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int strip = (k % sgroups) * p.strips_per_block + wv;
+  const long long grp = (long long)(k / sgroups) * 8 + xcd;  // (image, band) group
+  if (grp >= p.n_images * p.ybands) return;
   if (strip >= p.nstrips) return;
-  const int yb = b % p.ybands;
-  const int n = b / p.ybands;
+  const int yb = (int)(grp % p.ybands);
+  const int n = (int)(grp / p.ybands);
   const int ox0 = strip * p.strip_w;
   const int bw = min(p.strip_w, p.oW - ox0);
   const int oy0 = (int)((long long)yb * p.oH / p.ybands);
@@ -481,7 +486,8 @@ int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
   resident(spb);
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   p.ybands = pick_ybands(p.n_images * sgroups, (double)aa_device_cu_count() * blocks_per_cu[spb], taps_h, q.H, q.oH);
-  const int64_t grid = p.n_images * (int64_t)p.ybands * sgroups;
+  const int64_t groups8 = (p.n_images * (int64_t)p.ybands + 7) / 8 * 8;  // whole rounds of the 8 XCDs (see the kernel)
+  const int64_t grid = groups8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk,
                      q.stream, (const uint8_t *)q.in - p.in_mis, (uint8_t *)q.out, (const char *)q.aw.table_dev,
