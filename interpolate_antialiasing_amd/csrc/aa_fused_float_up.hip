@@ -36,6 +36,7 @@ struct FusedF32UpParams {
   int nseg, seg_bytes;
   int in_mis;
   unsigned long long plane_in_bytes, plane_out_bytes, total_in_bytes, total_out_bytes;
+  long long n_groups;  // (plane, band) groups = planes * ybands
 };
 
 __device__ inline void wait_vmcnt_up(int n) {  // rounding n DOWN only waits longer
@@ -61,13 +62,16 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int b = blockIdx.x;
+  // XCD-aware index mapping (see aa_fused_u8_v3_impl.h): workgroup id = 8 * k + xcd; within an XCD consecutive k walk
+  // the strips of one (plane, band) group first, so neighbouring strips meet in the same L2
   const int sgroups = (p.nstrips + p.strips_per_block - 1) / p.strips_per_block;
-  const int strip = (b % sgroups) * p.strips_per_block + wv;
-  b /= sgroups;
+  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int strip = (k % sgroups) * p.strips_per_block + wv;
+  const long long grp = (long long)(k / sgroups) * 8 + xcd;
+  if (grp >= p.n_groups) return;  // the grid is padded to whole rounds of 8 groups
   if (strip >= p.nstrips) return;
-  const int yb = b % p.ybands;
-  const int plane = b / p.ybands;  // n * C + c
+  const int yb = (int)(grp % p.ybands);
+  const int plane = (int)(grp / p.ybands);  // n * C + c
   const int ox0 = strip * p.strip_w;
   const int bw = min(p.strip_w, p.oW - ox0);
   const int oy0 = (int)((long long)yb * p.oH / p.ybands);
@@ -268,7 +272,8 @@ int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   const int64_t planes = q.N * q.C;
   p.ybands = pick_ybands_up(planes * sgroups, (double)aa_device_cu_count() * blocks_per_cu[spb], taps_h, q.H, q.oH);
-  const int64_t grid = planes * (int64_t)p.ybands * sgroups;
+  p.n_groups = planes * (int64_t)p.ybands;
+  const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream,
                      (const float *)((const uint8_t *)q.in - p.in_mis), (float *)q.out, (const char *)q.aw.table_dev,
