@@ -62,6 +62,11 @@ namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// cache policy of the output stores of the interleaved-channel kernels: nt (streaming).  Their 192-byte pieces are whole
+// 64-byte sectors, written once and never read here: -2 % against the default policy (sc0 alone changes nothing).  The
+// planar kernel's 64-byte pieces and the fp32 kernels' 244-byte pieces get SLOWER with nt (0.55 -> 0.59 / 0.62 ms): default.
+constexpr int kStoreAuxInterleaved = 2;
+
 
 
 __device__ inline unsigned pack4_clip8(int a0, int a1, int a2, int a3) {  // semantics: see aa_fused_u8.hip
@@ -266,18 +271,18 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xF, 0xF, false);
       const unsigned dw = __builtin_amdgcn_perm(nb, t, perm_sel);
       if (store_lane && (AA_V3_ABL != 1 || dw == 0x12345678u))
-        __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, AA_V3_ABL == 9 ? 0u : (unsigned)oy * out_row_bytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, AA_V3_ABL == 9 ? 0u : (unsigned)oy * out_row_bytes, C == 1 ? 0 : kStoreAuxInterleaved);
     } else if constexpr (C == 1) {
       const unsigned t = FLT ? trunc8(A[0][0]) * 0x01010101u : pack4_clip8(A[0][0], A[0][0], A[0][0], A[0][0]);  // the lane's byte, replicated
       const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x55 /*quad_perm:[1,1,1,1]*/, 0xF, 0xF, false);
       const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xAA /*quad_perm:[2,2,2,2]*/, 0xF, 0xF, false);
       const unsigned n3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xFF /*quad_perm:[3,3,3,3]*/, 0xF, 0xF, false);
       const unsigned dw = (t & 0x000000ffu) | (n1 & 0x0000ff00u) | (n2 & 0x00ff0000u) | (n3 & 0xff000000u);
-      if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+      if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, C == 1 ? 0 : kStoreAuxInterleaved);
     } else {
       const unsigned dw = FLT ? (trunc8(A[0][0]) | (trunc8(A[0][1]) << 8) | (trunc8(A[0][2]) << 16) | (trunc8(A[0][C - 1]) << 24))
                               : pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][C - 1]);
-      if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+      if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)oy * out_row_bytes, C == 1 ? 0 : kStoreAuxInterleaved);
     }
 #pragma unroll
     for (int k = 0; k + 1 < MAXC; k++)
