@@ -122,6 +122,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   const long long grp = (long long)(k / sgroups) * 8 + xcd;  // (image, band) group
   if (grp >= p.n_images * p.ybands) return;
   if (strip >= p.nstrips) return;
+  // (the pacing barrier below is only used by workgroups all of whose waves are alive: a short last group skips it)
+  const bool full_group = (k % sgroups + 1) * p.strips_per_block <= p.nstrips;
   const int yb = (int)(grp % p.ybands);
   const int n = (int)(grp / p.ybands);
   const int ox0 = strip * p.strip_w;
@@ -385,8 +387,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     if (x0 + 2 * G <= n_rows) {  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
       // Not a data dependence: once per G rows the strips of a band line up, so that the 192-byte pieces they store into
       // the same output rows reach L2 within a few microseconds of each other and leave it as whole lines (measured
-      // -2 %; every strip of the workgroup runs the same number of groups, finished waves do not count).
-      __builtin_amdgcn_s_barrier();
+      // -2 %; every strip of the workgroup runs the same number of groups).
+      if (full_group) __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int i = 0; i < G; i++) {
         if (AA_V3_ABL != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_row * (G - 2)) : "memory");

@@ -344,6 +344,8 @@ def test_fused_kernels_match_generic_at_full_size(aa):
               (harness(aa.nearest_forward), x8[:8], [196, 320]), (harness(aa.linear_forward), x8t[:4], [320, 196]),
               (harness(aa.cubic_forward), x4, [150, 252]), (harness(aa.linear_forward), x8[:2], [438, 320]),
               (harness(aa.linear_forward), x8p[:4], [196, 320]), (harness(aa.cubic_forward), x8p[:2], [196, 320])]  # test.py's layout
+    xw = torch.randint(0, 256, (2, 120, 1700, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)  # wide: 10 strips, short last group
+    cases += [(aa.linear_forward, xw, [60, 600]), (harness(aa.linear_forward), xw, [60, 600]), (aa.linear_forward, xw.contiguous(), [60, 600])]
     xf = torch.rand(6, 3, 438, 906, device="cuda") * 255
     cases += [(aa.linear_forward, xf, [196, 320]), (aa.cubic_forward, xf, [196, 320]), (aa.nearest_forward, xf, [196, 320])]
     xc = torch.rand(3, 3, 1024, 1024, device="cuda") * 255                                              # config 2 shape
