@@ -184,7 +184,7 @@ def secondary_configs(dev):
     return res
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -196,14 +196,74 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short timings of the other BASELINE configs")
-    args = ap.parse_args()
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="exercise the rank launcher only: every rank prints its rendezvous environment and exits before any "
+                         "GPU call; rank 0 also prints the bench line's skeleton (n_gpus, global_batch).  Runs without a GPU.")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0 = pick a free one)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run around it: this parent, which has NOT touched
+    the GPU (no torch.cuda call, no HIP call: importing torch does not initialise it), starts N fresh rank processes of
+    this same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, waits for all of them, forwards
+    rank 0's stdout (the single JSON line) and exits non-zero if any rank did.  Nothing is exec'ed over a live process."""
+    import socket
+    import subprocess
+
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE, stderr=None if rank == 0 else subprocess.PIPE, text=True))
+    rc = 0
+    outs = []
+    for rank, p in enumerate(procs):
+        out, err = p.communicate()
+        outs.append(out)
+        if p.returncode != 0:
+            rc = rc or p.returncode or 1
+            sys.stderr.write(f"[bench launcher] rank {rank} exited with {p.returncode}\n{(err or '')[-2000:]}\n")
+    if args.launch_dry_run:  # every rank's environment line, rank order
+        for out in outs:
+            sys.stdout.write(out)
+    else:
+        sys.stdout.write(outs[0])
+    sys.stdout.flush()
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args, argv))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and args.gpus != 1:  # (--gpus left at its default under torchrun: the environment decides)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with `python bench.py --gpus N` (self-launching) "
+                         f"or `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N`")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.launch_dry_run:  # before any GPU call
+        line = {"dry_run": True, "rank": rank, "local_rank": local_rank, "world": world,
+                "master": f"{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '')}"}
+        if rank == 0:
+            line.update({"n_gpus": world, "config": {"batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                                                     "parallelism": f"batch-shard x{world}"}, "scaling": "weak"})
+        print(json.dumps(line), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -79,7 +79,10 @@ typedef struct aa_table_header {
   int32_t scatter_off;   /* byte offset of the scatter section (0 = none), see below */
   int32_t scatter_ksize; /* row pitch of the scatter weights */
   int32_t scatter_max;   /* max outputs fed by one input index, filled by the device kernel */
-  int32_t reserved[4];
+  int32_t span64p1;      /* 1 + max_i (xmin[min(i+63,out-1)] - xmin[i]): how far the window starts of 64 consecutive outputs
+                            spread, measured by the device kernel from the table itself (explicit scale factors and
+                            align_corners make it differ from 63*in/out); 0 = not measured */
+  int32_t reserved[3];
 } aa_table_header;
 /* Scatter section (AA_TABLE_PIL and AA_TABLE_F32 tables), used by the fused kernels whose vertical pass runs in registers:
  * one 32-byte record per INPUT index x (in_size + 1 records; the last is an all-zero sentinel a reader may prefetch):
@@ -100,7 +103,8 @@ typedef struct aa_axis {
   int32_t scatter_off;   /* from the table header (aa_table_query); 0 = no scatter section */
   int32_t scatter_ksize;
   int32_t scatter_max;
-  int32_t reserved;
+  int32_t span64p1;      /* from the table header; 0 = unknown: the fused single-launch kernels then decline (they size
+                            their staged row segments from it) and the generic two-launch path runs */
 } aa_axis;
 
 /* Version / diagnostics. */
@@ -174,6 +178,10 @@ size_t aa_workspace_bytes_bwd(int dtype, int layout, int64_t N, int64_t C, int64
  * for aa_resample_fwd except u8 with AA_TABLE_F32 (the harness mode needs a float intermediate). */
 int aa_resample_axis_fwd(const void *in_dev, void *out_dev, int dtype, int64_t outer, int64_t in_size, int64_t inner,
                          const aa_axis *ax, aa_stream_t stream);
+
+/* Device-to-device copy of `bytes` bytes (16-byte vector loads/stores, grid-stride) enqueued on `stream`: the probe
+ * bench.py times on the box to report the attainable HBM copy ceiling next to the 8 TB/s spec peak. */
+int aa_probe_copy(const void *src_dev, void *dst_dev, size_t bytes, aa_stream_t stream);
 
 /* Kernel selection, process-wide; returns the previous setting.  1 (default): fused single-launch kernels, newest
  * design first; 2: first-generation fused kernels only (A/B measurements); 0: none.

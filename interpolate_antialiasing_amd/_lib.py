@@ -26,7 +26,7 @@ EXPORTS = (
     "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build_bytes", "aa_table_build",
     "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_workspace_bytes", "aa_resample_fwd",
     "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_resample_axis_fwd", "aa_set_fused",
-    "aa_last_variant",
+    "aa_last_variant", "aa_probe_copy",
 )
 
 
@@ -35,7 +35,7 @@ class TableHeader(ctypes.Structure):
         ("magic", ctypes.c_int32), ("filter", ctypes.c_int32), ("kind", ctypes.c_int32), ("in_size", ctypes.c_int32),
         ("out_size", ctypes.c_int32), ("ksize", ctypes.c_int32), ("align_corners", ctypes.c_int32),
         ("max_taps", ctypes.c_int32), ("transposed", ctypes.c_int32), ("scatter_off", ctypes.c_int32),
-        ("scatter_ksize", ctypes.c_int32), ("scatter_max", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4),
+        ("scatter_ksize", ctypes.c_int32), ("scatter_max", ctypes.c_int32), ("span64p1", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
     ]
 
 
@@ -44,7 +44,7 @@ class Axis(ctypes.Structure):
         ("table_dev", ctypes.c_void_p), ("in_size", ctypes.c_int32), ("out_size", ctypes.c_int32),
         ("ksize", ctypes.c_int32), ("max_taps", ctypes.c_int32), ("kind", ctypes.c_int32), ("filter", ctypes.c_int32),
         ("scatter_off", ctypes.c_int32), ("scatter_ksize", ctypes.c_int32), ("scatter_max", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("span64p1", ctypes.c_int32),
     ]
 
 
@@ -100,6 +100,8 @@ def load() -> ctypes.CDLL:
     L.aa_resample_axis_fwd.argtypes = [vp, vp, i32, i64, i64, i64, ax, vp]
     L.aa_resample_axis_fwd.restype = i32
     L.aa_last_variant.restype = ctypes.c_char_p
+    L.aa_probe_copy.argtypes = [vp, vp, sz, vp]
+    L.aa_probe_copy.restype = i32
     L.aa_set_fused.argtypes = [i32]
     L.aa_set_fused.restype = i32
     if L.aa_abi_version() != 1:

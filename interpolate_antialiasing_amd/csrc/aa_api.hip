@@ -197,10 +197,10 @@ size_t aa_workspace_bytes(int dtype, int layout, int64_t N, int64_t C, int64_t H
   (void)oH;
   if (!ax_h || !ax_w || N <= 0) return 0;
   if (g_fused_enabled) {
-    if (g_fused_enabled == 1 && aa_fused_u8_v3_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
-    if (aa_fused_u8_nhwc_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
-    if (aa_fused_float_nchw_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
-    if (aa_fused_float_nchw_up_applicable(dtype, layout, C, H, W, ax_h, ax_w)) return 0;
+    if (g_fused_enabled == 1 && aa_fused_u8_v3_applicable(dtype, layout, N, C, H, W, ax_h, ax_w)) return 0;
+    if (aa_fused_u8_nhwc_applicable(dtype, layout, N, C, H, W, ax_h, ax_w)) return 0;
+    if (aa_fused_float_nchw_applicable(dtype, layout, N, C, H, W, ax_h, ax_w)) return 0;
+    if (aa_fused_float_nchw_up_applicable(dtype, layout, N, C, H, W, ax_h, ax_w)) return 0;
   }
   return aa_generic_workspace_bytes(dtype, ax_w->kind, N, C, H, oW);
 }
@@ -309,6 +309,12 @@ int aa_resample_axis_fwd(const void *in_dev, void *out_dev, int dtype, int64_t o
   if (!in_dev || !out_dev) return AA_ERR_NULL;
   g_last_variant = "generic_axis";
   return aa_launch_axis_fwd(in_dev, out_dev, dtype, outer, in_size, inner, *ax, (hipStream_t)stream);
+}
+
+int aa_probe_copy(const void *src_dev, void *dst_dev, size_t bytes, aa_stream_t stream) {
+  if (!src_dev || !dst_dev) return AA_ERR_NULL;
+  if ((((uintptr_t)src_dev | (uintptr_t)dst_dev) & 15) != 0) return AA_ERR_BAD_SHAPE;
+  return aa_launch_probe_copy(src_dev, dst_dev, bytes, (hipStream_t)stream);
 }
 
 int aa_set_fused(int enabled) {

@@ -77,11 +77,44 @@ int aa_try_fused_u8_nhwc(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw_up(const AAProblem &p, const char **variant);  // H <= oH: adjoint (gather form), up-scaling
 int aa_try_fused_u8_nhwc_v3(const AAProblem &p, const char **variant);  // LDS-DMA staged, wave-autonomous, V pass in registers
-bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
-bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
-bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
-bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
+// The *_applicable predicates hold EVERY reason a fused path can decline that does not depend on the pointers (shape, LDS
+// size, grid size, dispatch widths): aa_workspace_bytes() answers 0 exactly when aa_resample_fwd() will not need one.
+bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
+bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
+bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
+bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
+// Input pixels the windows (tw taps each) of one strip of <= 64 consecutive outputs cover, from the spread the table
+// kernel MEASURED (header.span64p1; explicit scale factors and align_corners make it differ from 63 * in / out).
+// -1 = unknown (a caller that did not fill aa_axis.span64p1): the fused kernels decline.
+inline int aa_strip_span_px(const aa_axis &aw, int tw) { return aw.span64p1 > 0 ? aw.span64p1 + tw : -1; }
+// (row bands never exceed 64, so a grid of `units * 64` workgroups bounds every launch)
+inline bool aa_grid_fits(int64_t units) { return units > 0 && units <= (int64_t)0x7FFFFFFF / 64 - 8; }
 // CU count of the current device (cached); 256 on MI355X
 int aa_device_cu_count();
+// Resident workgroups per CU of `kern` at `threads` threads and `lds` bytes of dynamic LDS, cached per (kernel, device,
+// threads, lds) behind a mutex — the occupancy query costs microseconds, and a B = 1 call is ~10 us end to end.  -1 when
+// the query fails (callers fall back to an estimate; it only feeds launch-shape heuristics, never results).
+#include <mutex>
+template <typename K>
+int aa_resident_blocks(K kern, int threads, size_t lds) {
+  struct Entry { int dev, threads; size_t lds; int nb; };
+  static std::mutex mu;
+  static Entry cache[32];
+  static int n = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < n; i++)
+    if (cache[i].dev == dev && cache[i].threads == threads && cache[i].lds == lds) return cache[i].nb;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb <= 0) {
+    (void)hipGetLastError();
+    nb = -1;
+  }
+  if (n < 32) cache[n++] = Entry{dev, threads, lds, nb};
+  return nb;
+}
+
+int aa_launch_probe_copy(const void *src, void *dst, size_t bytes, hipStream_t stream);
 // scatter-add adjoint
 int aa_launch_bwd_atomic(const AAProblem &p);

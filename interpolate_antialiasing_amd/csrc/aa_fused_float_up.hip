@@ -253,14 +253,15 @@ int pick_ybands_up(int64_t items_per_band, double slots, int taps_h, int64_t H, 
 template <int TW, int G, int KR>
 int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
   auto kern = fused_f32_nchw_up_kernel<TW, G, KR>;
-  static int blocks_per_cu[9] = {0};
-  auto resident = [&](int s) {  // workgroups of s strips a CU holds
-    if (blocks_per_cu[s] == 0) {
-      int nb = 0;
-      if (lds * s > 64 * 1024 || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * s, lds * s) != hipSuccess || nb <= 0) nb = -1;
-      blocks_per_cu[s] = nb;
+  auto resident = [&](int s) {  // workgroups of s strips a CU holds (-1: their rings do not fit a workgroup's LDS)
+    if (lds * s > 64 * 1024) return -1;  // (never for s == 1: a strip's ring is at most 16 KiB)
+    int nb = aa_resident_blocks(kern, 64 * s, lds * s);
+    if (nb <= 0) {  // a failed query only costs the heuristic its input: estimate from LDS and wave slots
+      nb = (int)((160 * 1024) / (lds * s > 0 ? lds * s : 1));
+      if (nb > 32 / s) nb = 32 / s;
+      if (nb < 1) nb = 1;
     }
-    return blocks_per_cu[s];
+    return nb;
   };
   // strips of a band share a workgroup unless single-strip workgroups put more waves on a CU (see aa_fused_u8_v3_impl.h)
   int spb = p.strips_per_block;
@@ -271,7 +272,7 @@ int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
   const size_t lds_blk = lds * spb;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   const int64_t planes = q.N * q.C;
-  p.ybands = pick_ybands_up(planes * sgroups, (double)aa_device_cu_count() * blocks_per_cu[spb], taps_h, q.H, q.oH);
+  p.ybands = pick_ybands_up(planes * sgroups, (double)aa_device_cu_count() * resident(spb), taps_h, q.H, q.oH);
   p.n_groups = planes * (int64_t)p.ybands;
   const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
@@ -291,9 +292,8 @@ int launch_kr(int kr, const FusedF32UpParams &p, const AAProblem &q, size_t lds)
 
 }  // namespace
 
-bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah,
+bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah,
                                        const aa_axis *aw) {
-  (void)C;
   if (dtype != AA_F32 || layout != AA_NCHW) return false;
   if (!ah || !aw || ah->kind != AA_TABLE_F32 || aw->kind != AA_TABLE_F32) return false;
   if (H > ah->out_size) return false;  // shrinking heights: aa_fused_float.hip
@@ -303,14 +303,14 @@ bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t C, int64_t
   const int tw = taps_w <= 2 ? 2 : (taps_w <= 4 ? 4 : 8);
   if (W < tw) return false;
   if ((uint64_t)H * W * 4 > 0xFFFFFFF0ull || (uint64_t)ah->out_size * aw->out_size * 4 > 0xFFFFFFF0ull) return false;
-  const double scale_w = (double)W / (double)aw->out_size;
-  const int span_px = (int)floor(63.0 * (scale_w > 0 ? scale_w : 0)) + 1 + tw;
-  if ((span_px * 4 + 15 + 15) / 16 > 64) return false;  // one DMA instruction per staged row
+  const int span_px = aa_strip_span_px(*aw, tw);
+  if (span_px < 0 || (span_px * 4 + 15 + 15) / 16 > 64) return false;  // one DMA instruction per staged row
+  if (!aa_grid_fits(N * C * ((aw->out_size + 63) / 64 + 1))) return false;
   return true;
 }
 
 int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
-  if (!aa_fused_float_nchw_up_applicable(q.dtype, q.layout, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
+  if (!aa_fused_float_nchw_up_applicable(q.dtype, q.layout, q.N, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   const int taps_w = q.aw.max_taps > 0 ? q.aw.max_taps : q.aw.ksize;
   const int tw = taps_w <= 2 ? 2 : (taps_w <= 4 ? 4 : 8);
@@ -328,8 +328,7 @@ int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   p.strip_w = (int)((q.oW + p.nstrips - 1) / p.nstrips);
   p.nstrips = (int)((q.oW + p.strip_w - 1) / p.strip_w);
   p.strips_per_block = p.nstrips <= 8 ? p.nstrips : 4;
-  const double scale_w = (double)q.W / (double)q.oW;
-  const int span_px = (int)floor(63.0 * (scale_w > 0 ? scale_w : 0)) + 1 + tw;
+  const int span_px = aa_strip_span_px(q.aw, tw);
   p.nseg = (span_px * 4 + 15 + 15) / 16;
   p.seg_bytes = p.nseg * 16;
   p.ybands = 1;

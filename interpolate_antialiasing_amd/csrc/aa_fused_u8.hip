@@ -275,7 +275,23 @@ int next_pow2(int v) {
 
 }  // namespace
 
-bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah,
+static void v1_geometry(int64_t C, int64_t H, int64_t oW, const aa_axis &ah, int *xbands_o, int *bw_o, int *ring_rows_o, int *pitch_o) {
+  // column bands: at most 1024 lanes, a multiple of 4 columns so every band starts dword-aligned
+  int xbands = (int)((oW + 1023) / 1024);
+  int bw = (int)((oW + xbands - 1) / xbands);
+  bw = (bw + 3) & ~3;
+  xbands = (int)((oW + bw - 1) / bw);
+  // ring depth: while slow waves still read chunk i's rows [ymin(first oy of chunk i), r_end(i)), fast waves may
+  // already write chunk i+1's rows [r_end(i), r_end(i+1)): span <= taps_h + 2*K*max(scale_h,1) (+ rounding slack)
+  const int taps_h = ah.max_taps > 0 ? ah.max_taps : ah.ksize;
+  const double scale_h = (double)H / (double)ah.out_size;
+  *ring_rows_o = taps_h + (int)(2.0 * kRowsPerBarrier * (scale_h > 1.0 ? scale_h : 1.0) + 0.999) + 4;
+  *pitch_o = ((bw * (int)C + 15) / 16) * 16;
+  *xbands_o = xbands;
+  *bw_o = bw;
+}
+
+bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah,
                                  const aa_axis *aw) {
   if (dtype != AA_U8 || layout != AA_NHWC) return false;
   if (!ah || !aw || ah->kind != AA_TABLE_PIL || aw->kind != AA_TABLE_PIL) return false;
@@ -287,11 +303,16 @@ bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t C, int64_t H, in
   if ((uint64_t)H * W * C > 0xFFFFFFF0ull) return false;  // 32-bit offsets inside one image
   const int taps_h = ah->max_taps > 0 ? ah->max_taps : ah->ksize;
   if (taps_h > 64) return false;
+  if (H >= (1 << 20)) return false;
+  int xbands, bw, ring_rows, pitch;
+  v1_geometry(C, H, aw->out_size, *ah, &xbands, &bw, &ring_rows, &pitch);
+  if ((size_t)ring_rows * pitch > 64 * 1024) return false;  // the intermediate ring must fit the workgroup's LDS
+  if (!aa_grid_fits(N * xbands)) return false;
   return true;
 }
 
 int aa_try_fused_u8_nhwc(const AAProblem &q, const char **variant) {
-  if (!aa_fused_u8_nhwc_applicable(q.dtype, q.layout, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
+  if (!aa_fused_u8_nhwc_applicable(q.dtype, q.layout, q.N, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
   if (((uintptr_t)q.out & 3) != 0) return 0;
   const int C = (int)q.C;
   const int taps_w = q.aw.max_taps > 0 ? q.aw.max_taps : q.aw.ksize;
@@ -309,22 +330,13 @@ int aa_try_fused_u8_nhwc(const AAProblem &q, const char **variant) {
   p.img_out_bytes = (unsigned long long)q.oH * q.oW * C;
   p.total_in_bytes = p.img_in_bytes * (unsigned long long)q.N;
 
-  // column bands: at most 1024 lanes, a multiple of 4 columns so every band starts dword-aligned
-  int xbands = (int)((q.oW + 1023) / 1024);
-  int bw = (int)((q.oW + xbands - 1) / xbands);
-  bw = (bw + 3) & ~3;
-  xbands = (int)((q.oW + bw - 1) / bw);
+  int xbands, bw, ring_rows, pitch;
+  v1_geometry(q.C, q.H, q.oW, q.ah, &xbands, &bw, &ring_rows, &pitch);
   const int block = ((bw + 63) / 64) * 64;
-  // ring depth: while slow waves still read chunk i's rows [ymin(first oy of chunk i), r_end(i)), fast waves may
-  // already write chunk i+1's rows [r_end(i), r_end(i+1)): span <= taps_h + 2*K*max(scale_h,1) (+ rounding slack)
-  const double scale_h = (double)q.H / (double)q.oH;
-  const int ring_rows = taps_h + (int)(2.0 * kRowsPerBarrier * (scale_h > 1.0 ? scale_h : 1.0) + 0.999) + 4;
   p.ring_rows = ring_rows;
   p.ring_magic = (unsigned)(0x100000000ull / (unsigned)ring_rows) + 1u;
-  if (q.H >= (1 << 20)) return 0;
-  p.pitch = ((bw * C + 15) / 16) * 16;
+  p.pitch = pitch;
   const size_t lds = (size_t)ring_rows * p.pitch;
-  if (lds > 64 * 1024) return 0;
 
   // row bands.  Every extra band re-reads and re-filters ~taps_h halo rows, but the grid must fill the chip's
   // resident-workgroup slots a near-integer number of times or the last partial round idles most CUs

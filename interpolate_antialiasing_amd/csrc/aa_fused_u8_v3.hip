@@ -4,7 +4,7 @@
 #include "aa_fused_u8_v3_impl.h"
 
 // Everything the kernel needs that can be known without the pointers (aa_workspace_bytes asks before they exist).
-static bool v3_shape_ok(int dtype, int layout, int64_t Cin, int64_t H, int64_t W, const aa_axis &ah, const aa_axis &aw, bool *flt_out,
+static bool v3_shape_ok(int dtype, int layout, int64_t N, int64_t Cin, int64_t H, int64_t W, const aa_axis &ah, const aa_axis &aw, bool *flt_out,
                         bool *planar_out, int *tw_out) {
   if (dtype != AA_U8) return false;
   const bool flt = ah.kind == AA_TABLE_F32 && aw.kind == AA_TABLE_F32;  // the reference harness's uint8 semantics
@@ -23,24 +23,26 @@ static bool v3_shape_ok(int dtype, int layout, int64_t Cin, int64_t H, int64_t W
   if (tw == 0 || W < tw) return false;
   if ((oW * C) % 4 != 0 || (C == 3 && oW % 4 != 0)) return false;
   if ((uint64_t)H * W * C > 0xFFFFFFF0ull || (uint64_t)oH * oW * C > 0xFFFFFFF0ull) return false;
-  const double scale_w = (double)W / (double)oW;
-  const int span_px = (int)floor(63.0 * (scale_w > 0 ? scale_w : 0)) + 1 + tw;
+  const int span_px = aa_strip_span_px(aw, tw);
+  if (span_px < 0) return false;
   const int nseg = (span_px * C + 3 + 15 + 15) / 16;
   if (nseg > 128 || (size_t)aa_v3_group() * nseg * 16 > 64 * 1024) return false;
+  const int64_t nstrips = (oW + 63) / 64 + 1;  // (balanced strips can be one more)
+  if (!aa_grid_fits((planar ? N * Cin : N) * nstrips)) return false;
   *flt_out = flt; *planar_out = planar; *tw_out = tw;
   return true;
 }
 
-bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw) {
+bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw) {
   bool flt, planar;
   int tw;
-  return ah && aw && v3_shape_ok(dtype, layout, C, H, W, *ah, *aw, &flt, &planar, &tw);
+  return ah && aw && v3_shape_ok(dtype, layout, N, C, H, W, *ah, *aw, &flt, &planar, &tw);
 }
 
 int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   bool flt, planar;
   int tw;
-  if (!v3_shape_ok(q.dtype, q.layout, q.C, q.H, q.W, q.ah, q.aw, &flt, &planar, &tw)) return 0;
+  if (!v3_shape_ok(q.dtype, q.layout, q.N, q.C, q.H, q.W, q.ah, q.aw, &flt, &planar, &tw)) return 0;
   const int C = planar ? 1 : (int)q.C;
   const int64_t NI = planar ? q.N * q.C : q.N;  // images the kernel sees
   if (((uintptr_t)q.out & 3) != 0) return 0;
@@ -68,8 +70,7 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   }
 
   // segment: bytes covered by 64 consecutive windows of one input row (+ alignment slack), see aa_fused_u8_v2.hip
-  const double scale_w = (double)q.W / (double)q.oW;
-  const int span_px = (int)floor(63.0 * (scale_w > 0 ? scale_w : 0)) + 1 + tw;
+  const int span_px = aa_strip_span_px(q.aw, tw);
   p.nseg = (span_px * C + 3 + 15 + 15) / 16;
   if (p.nseg > 128) return 0;
   p.seg_bytes = p.nseg * 16;

@@ -473,14 +473,10 @@ int pick_ybands(int64_t items_per_band, double slots, int taps_h, int64_t H, int
 template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC, bool FLT = false>
 int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
   auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC, FLT>;
-  static int blocks_per_cu[9] = {0};  // resident workgroups per CU for this instantiation, by waves per workgroup
-  auto resident = [&](int s) {
-    if (blocks_per_cu[s] == 0) {
-      int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * s, lds * s) != hipSuccess || nb <= 0) nb = 16 / s;
-      blocks_per_cu[s] = nb < 1 ? 1 : nb;
-    }
-    return blocks_per_cu[s];
+  auto resident = [&](int s) {  // resident workgroups of s strips per CU for this instantiation and this problem's LDS
+    int nb = aa_resident_blocks(kern, 64 * s, lds * s);
+    if (nb <= 0) nb = 16 / s;
+    return nb < 1 ? 1 : nb;
   };
   // Strips of a band share a workgroup (neighbouring segments share sectors, their stores meet in L2) unless that leaves
   // wave slots of the CU empty: 5 strips -> 4 workgroups = 20 of 24 waves, and 24 single-strip workgroups are 5 % faster;
@@ -490,9 +486,8 @@ int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
   p.strips_per_block = spb;
   const int sgroups = (p.nstrips + spb - 1) / spb;
   const size_t lds_blk = lds * spb;
-  resident(spb);
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
-  p.ybands = pick_ybands(p.n_images * sgroups, (double)aa_device_cu_count() * blocks_per_cu[spb], taps_h, q.H, q.oH);
+  p.ybands = pick_ybands(p.n_images * sgroups, (double)aa_device_cu_count() * resident(spb), taps_h, q.H, q.oH);
   const int64_t groups8 = (p.n_images * (int64_t)p.ybands + 7) / 8 * 8;  // whole rounds of the 8 XCDs (see the kernel)
   const int64_t grid = groups8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;

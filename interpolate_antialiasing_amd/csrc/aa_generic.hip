@@ -206,3 +206,23 @@ int aa_launch_axis_fwd(const void *in, void *out, int dtype, int64_t outer, int6
   if (dtype == AA_BF16 && ax.kind == AA_TABLE_F32) return run_axis<PipeF32, bf16_t>(in, out, outer, in_size, inner, ax, stream);
   return AA_ERR_BAD_DTYPE;
 }
+
+
+// ---- HBM copy-ceiling probe (bench.py: "measure the attainable ceiling on the box") -----------------------
+namespace {
+__global__ void __launch_bounds__(256) probe_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+int aa_launch_probe_copy(const void *src, void *dst, size_t bytes, hipStream_t stream) {
+  const size_t n16 = bytes / 16;
+  if (n16 == 0) return AA_OK;
+  size_t blocks = (n16 + 255) / 256;
+  const size_t cap = (size_t)aa_device_cu_count() * 32;  // 8 waves per SIMD's worth of 256-thread workgroups, grid-stride beyond
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4 *)src, (uint4 *)dst, n16);
+  AA_HIP_CHECK_LAUNCH();
+  return AA_OK;
+}

@@ -152,6 +152,19 @@ __global__ void table_build_pil(int filter, int in_size, int out_size, int ksize
   atomicMax(max_taps, (int32_t)(xmax > 1 ? xmax : 1));
 }
 
+// header.span64p1 = 1 + max_i (xmin[min(i+63, out-1)] - xmin[i]): the fused kernels stage, per strip of <= 64 consecutive
+// outputs, the input range their windows cover; they size that range from this MEASURED spread (an explicit scale
+// factor or align_corners moves the windows apart differently from in/out).  Runs after the table's own kernel.
+__global__ void table_span_kernel(char *table, int out_size) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= out_size) return;
+  const int32_t *xmin = (const int32_t *)(table + aa_table_xmin_off());
+  const int j = i + 63 < out_size ? i + 63 : out_size - 1;
+  int d = xmin[j] - xmin[i];
+  if (d < 0) d = 0;
+  atomicMax(&((aa_table_header *)table)->span64p1, d + 1);
+}
+
 __global__ void table_write_header(aa_table_header h, char *table) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *(aa_table_header *)table = h;
 }
@@ -187,7 +200,7 @@ __global__ void table_transpose_kernel(const char *fwd, int32_t *tmin, int32_t *
   int cnt = lo - first;
   if (cnt < 0) cnt = 0;
   if (cnt > tr_ksize) cnt = tr_ksize;  // cannot happen when tr_ksize comes from aa_table_transposed_ksize
-  tmin[x] = cnt > 0 ? first : 0;
+  tmin[x] = cnt > 0 ? first : (first < out_size ? first : out_size - 1);  // (kept monotone: the span measurement and the fused kernels' segments rely on it)
   tsize[x] = cnt;
   int k = 0;
   for (; k < cnt; k++) {
@@ -251,6 +264,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
   h.scatter_off = 0;
   h.scatter_ksize = 0;
   h.scatter_max = 0;
+  h.span64p1 = 0;
   if ((kind == AA_TABLE_PIL || kind == AA_TABLE_F32) && scatter_ksize > 0) {
     h.scatter_off = (int32_t)aa_table_total_bytes(kind, out_size, ksize);
     h.scatter_ksize = scatter_ksize;
@@ -283,6 +297,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
                          ksize);
     }
   }
+  hipLaunchKernelGGL(table_span_kernel, dim3(blocks), dim3(threads), 0, stream, t, (int)out_size);
   AA_HIP_CHECK_LAUNCH();
   return AA_OK;
 }
@@ -295,6 +310,10 @@ int aa_launch_table_transpose(const aa_table_header &fh, const void *table_dev, 
   h.ksize = tr_ksize;
   h.max_taps = 0;
   h.transposed = 1;
+  h.scatter_off = 0;  // the adjoint table has no scatter section (its buffer is sized by aa_table_bytes)
+  h.scatter_ksize = 0;
+  h.scatter_max = 0;
+  h.span64p1 = 0;
   char *t = (char *)tr_dev;
   hipLaunchKernelGGL(table_write_header, dim3(1), dim3(64), 0, stream, h, t);
   const int threads = 128;
@@ -311,6 +330,7 @@ int aa_launch_table_transpose(const aa_table_header &fh, const void *table_dev, 
   } else {
     return AA_ERR_BAD_DTYPE;
   }
+  hipLaunchKernelGGL(table_span_kernel, dim3(blocks), dim3(threads), 0, stream, t, fh.in_size);
   AA_HIP_CHECK_LAUNCH();
   return AA_OK;
 }

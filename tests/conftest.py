@@ -42,3 +42,8 @@ def golden_pil():
 @pytest.fixture(scope="session")
 def golden_backward():
     return load_golden("backward.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_harness():
+    return load_golden("harness_pil.npz")

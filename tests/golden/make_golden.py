@@ -33,7 +33,39 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
+HARNESS_SIZES = [(320, 196), (460, 220), (120, 96), (1200, 196), (120, 1200)]  # (W, H): the reference's test.py:15-21
+
+
+def make_harness():
+    """6. What the reference's harness compares against (test.py:336,370-379): PIL.Image.resize of data/test.png at the five
+    (W, H) sizes of test.py:15-21, bilinear and bicubic -> harness_pil.npz.  Also checks, right here, that the reference build
+    driven the way test.py drives it (float(), op, clamp for bicubic, byte()) meets test.py's thresholds on every size and that
+    the oracle's restatements agree with it / with Pillow bit for bit."""
+    ref = oracle.load_ref("ref_s22")
+    assert ref is not None, "run `make -C oracle ref` first"
+    img = np.asarray(Image.open(os.path.join(REF_DATA, "test.png")).convert("RGB")).copy()
+    chw = img.transpose(2, 0, 1)[None]
+    out = {}
+    for (w, h) in HARNESS_SIZES:
+        for filt, res, fn in (("linear", Image.BILINEAR, ref.linear_forward), ("cubic", Image.BICUBIC, ref.cubic_forward)):
+            pil = np.asarray(Image.fromarray(img).resize((w, h), resample=res))
+            out[f"pil_{filt}_{w}x{h}"] = pil
+            y = fn(t(chw).float(), [h, w], False)
+            if filt == "cubic":
+                y = torch.clamp(y, 0, 255)
+            proto = y[0].byte().permute(1, 2, 0).numpy()
+            err = np.abs(proto.astype(np.float64) - pil.astype(np.float64))
+            assert err.mean() < 1.0 and err.max() < (1.0 + 1e-5 if filt == "linear" else 20.0), (filt, w, h, err.mean(), err.max())
+            assert np.array_equal(oracle.harness_u8(filt, chw, (h, w))[0].transpose(1, 2, 0), proto), (filt, w, h)
+            assert np.array_equal(oracle.pil_resize_u8(filt, chw, (h, w))[0].transpose(1, 2, 0), pil), (filt, w, h)
+            out[f"refmae_{filt}_{w}x{h}"] = np.float64(err.mean())
+    np.savez_compressed(os.path.join(HERE, "harness_pil.npz"), **out)
+    print("harness: PIL outputs of test.png at", len(HARNESS_SIZES), "sizes x {bilinear, bicubic}; reference build within test.py's thresholds")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "harness":
+        return make_harness()
     ref = oracle.load_ref("ref_s22")
     ref3 = oracle.load_ref("ref_s3")
     ref3s = oracle.load_ref("ref_s3sep")
@@ -174,6 +206,7 @@ def main():
         assert np.array_equal(oracle.legacy_nonaa_linear_backward(go.astype(np.float32), (H, W)), leg)
     np.savez_compressed(os.path.join(HERE, "backward.npz"), **bw)
     print("backward: true-adjoint (fp64 autograd) + legacy non-AA pinned")
+    make_harness()
 
 
 if __name__ == "__main__":

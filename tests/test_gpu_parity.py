@@ -604,3 +604,94 @@ def test_hip_graph_capture_and_replay(aa):
         torch.cuda.synchronize()
         assert torch.equal(y, aa.linear_forward(xs, [196, 320]))
         assert torch.equal(gi, aa.linear_backward(gs, [196, 320], [2, 3, 438, 906]))
+
+
+# ------------------------------------------------------------------------------------------------ §8f-1: the reference's harness
+@pytest.mark.parametrize("mode,filt", [("bilinear", "linear"), ("bicubic", "cubic")])
+def test_harness_five_sizes_vs_pil(aa, golden_kat, golden_harness, mode, filt):
+    """The reference's own check (test.py:334-379) on its own image at its five (W, H) sizes (test.py:15-21), through
+    tools/harness.py's logic: test.py's flow (float(), op, clamp for bicubic, byte()) must meet test.py's thresholds against
+    PIL (MAE < 1, max < 1 + 1e-5 bilinear / < 20 bicubic, :370-379) and equal the oracle's harness restatement bit for bit;
+    the Pillow-exact mode must equal PIL's committed output bit for bit.  Includes both up-scaling sizes ((1200, 196) widens,
+    (120, 1200) heightens: the uint8 kernels' gather-form vertical pass)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import harness
+
+    rgb = golden_kat["rgb"]
+    chw = np.ascontiguousarray(rgb.transpose(2, 0, 1))[None]
+    fn = _fn(aa, filt)
+    assert harness.SIZES == [(320, 196), (460, 220), (120, 96), (1200, 196), (120, 1200)]
+    for (w, h) in harness.SIZES:
+        pil = golden_harness[f"pil_{filt}_{w}x{h}"]
+        r = harness.evaluate(rgb, (w, h), mode, "harness", pil_dn=pil)
+        assert r["mae"] < harness.THRESHOLDS[mode][0] and r["max"] < harness.THRESHOLDS[mode][1], (w, h, r["mae"], r["max"])
+        assert abs(r["mae"] - float(golden_harness[f"refmae_{filt}_{w}x{h}"])) < 1e-12, (w, h)  # the reference build's own MAE
+        exp = oracle.harness_u8(filt, chw, (h, w))[0].transpose(1, 2, 0)
+        assert np.array_equal(r["proto"], exp), (w, h, r["variant"])
+        # the shim's fused form of the same semantics (uint8 in, uint8 out) in both layouts
+        for cl in (False, True):
+            y = fn(_gpu(chw, cl), [h, w], False, uint8_mode="harness")
+            assert np.array_equal(y[0].permute(1, 2, 0).cpu().numpy(), exp), (w, h, cl)
+        p = harness.evaluate(rgb, (w, h), mode, "pil", pil_dn=pil)
+        assert p["max"] == 0.0 and np.array_equal(p["proto"], pil), (w, h, p["variant"])
+        ycl = fn(_gpu(chw, True), [h, w], False)  # channels_last = what PIL itself holds (HWC)
+        assert np.array_equal(ycl[0].permute(1, 2, 0).cpu().numpy(), pil), (w, h)
+
+
+def test_fused_segments_follow_the_tables_scale(aa):
+    """Staged row segments are sized from the spread of the table's own window starts (header.span64p1), not from W/oW:
+    an explicit scale factor with 1/s > W/oW, or align_corners when down-scaling, spreads 64 consecutive windows further
+    apart than 63*W/oW.  Fused == generic bit for bit, with oW >= 64 so that a strip really spans 64 outputs."""
+    from interpolate_antialiasing_amd import _lib, tables
+
+    torch.manual_seed(11)
+    xf = torch.rand(2, 3, 120, 906, device="cuda") * 255
+    x8 = torch.randint(0, 256, (2, 120, 906, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
+    t0 = tables.build_table(_lib.FILTER_LINEAR, _lib.TABLE_F32, 906, 320, False, 0.0, torch.device("cuda"))
+    t1 = tables.build_table(_lib.FILTER_LINEAR, _lib.TABLE_F32, 906, 320, False, 0.30, torch.device("cuda"))
+    xmin1 = t1.unpack()[0]
+    assert t1.span64p1 == 1 + int((xmin1[63:] - xmin1[:-63]).max()) and t1.span64p1 > t0.span64p1 + 20
+    calls = [
+        (lambda: aa.linear_forward(xf, [50, 320], scale_factors=[0.0, 0.30]), "fused_f32_nchw"),        # 1/0.30 = 3.33 > 2.83
+        (lambda: aa.cubic_forward(xf, [50, 320], scale_factors=[0.0, 0.30]), "fused_f32_nchw"),
+        (lambda: aa.linear_forward(x8, [50, 320], uint8_mode="harness", scale_factors=[0.0, 0.30]), "fused_u8_nhwc_harness_v3"),
+        (lambda: aa.linear_forward(x8, [50, 320], True, uint8_mode="harness"), "fused_u8_nhwc_harness_v3"),  # align_corners
+        (lambda: aa.linear_forward(xf, [50, 320], True), "fused_f32_nchw"),                               # (W-1)/(oW-1) > W/oW
+        (lambda: aa.linear_forward(xf, [300, 320], scale_factors=[0.0, 0.30]), "fused_f32_nchw_up"),     # heights grow
+    ]
+    try:
+        for fn, want in calls:
+            _lib.set_fused(1)
+            y1 = fn()
+            assert _lib.last_variant() == want, (_lib.last_variant(), want)
+            _lib.set_fused(0)
+            y0 = fn()
+            assert _lib.last_variant().startswith("generic")
+            assert torch.equal(y1, y0), want
+    finally:
+        _lib.set_fused(1)
+
+
+def test_workspace_answer_matches_dispatch(aa):
+    """aa_workspace_bytes() says 0 exactly when aa_resample_fwd() will not ask for one: thumbnail shapes whose windows (13-16
+    taps) are too wide for the newest uint8 kernel and whose intermediate ring is too big for the first one must run the
+    generic path with a workspace instead of failing (uint8 channels_last bicubic 1750 -> 500, bilinear 2400 -> 400)."""
+    from interpolate_antialiasing_amd import _lib
+
+    torch.manual_seed(12)
+    for fn, shape, size in ((aa.cubic_forward, (2, 1750, 1750, 3), [500, 500]), (aa.linear_forward, (1, 300, 2400, 3), [50, 400]),
+                            (aa.linear_forward, (1, 2400, 2400, 3), [400, 400]), (aa.cubic_forward, (1, 700, 1400, 4), [100, 200])):
+        x = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
+        y = fn(x, size)
+        v = _lib.last_variant()
+        try:
+            _lib.set_fused(0)
+            y0 = fn(x, size)
+        finally:
+            _lib.set_fused(1)
+        assert torch.equal(y, y0), (shape, size, v)
+        exp = oracle.pil_resize_u8("cubic" if fn is aa.cubic_forward else "linear", x[:1].cpu().numpy(), tuple(size))
+        assert np.array_equal(y[:1].cpu().numpy(), exp), (shape, size, v)

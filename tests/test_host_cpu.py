@@ -191,3 +191,28 @@ def test_table_broadcast_and_sharding_gloo_world2(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert f"worker {rank} ok" in out
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus N` (no torch.distributed.run around it) starts N fresh rank processes itself, before any GPU
+    call: each rank sees its RANK / WORLD_SIZE / MASTER_* and the bench line's skeleton carries n_gpus = N and
+    global_batch = N x batch.  --launch-dry-run makes the ranks exit before touching a GPU, so this runs on the CPU box."""
+    import json
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--launch-dry-run"],
+                         capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items()
+                                                                           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [l["rank"] for l in lines] == [0, 1] and all(l["world"] == 2 and l["dry_run"] for l in lines)
+    assert lines[0]["master"] == lines[1]["master"] and lines[0]["master"].startswith("127.0.0.1:")
+    assert lines[0]["n_gpus"] == 2 and lines[0]["config"]["global_batch"] == 128 and lines[0]["scaling"] == "weak"
+    # under torch.distributed.run the environment carries the world: the same script is then a rank, not a launcher
+    env = dict(os.environ, RANK="1", LOCAL_RANK="1", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-dry-run"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode == 0 and json.loads(out.stdout)["rank"] == 1 and json.loads(out.stdout)["world"] == 4
+    # a world that contradicts --gpus is refused, naming the right commands
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-dry-run"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "torch.distributed.run" in out.stderr

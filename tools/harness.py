@@ -23,6 +23,38 @@ import torch  # noqa: E402
 SIZES = [(320, 196), (460, 220), (120, 96), (1200, 196), (120, 1200)]  # (W, H), test.py:15-21
 
 
+THRESHOLDS = {"bilinear": (1.0, 1.0 + 1e-5), "bicubic": (1.0, 20.0)}  # (MAE, max abs err) vs PIL: test.py:370-372, :377-379
+
+
+def evaluate(rgb, size, mode="bilinear", uint8_mode="harness", pil_dn=None):
+    """One size of the reference's check (test.py:334-379) on the GPU: resize the HWC uint8 image `rgb` to size = (W, H) and
+    compare with PIL.  uint8_mode "harness" does what test.py does around the op (float(), op, clamp for bicubic, byte());
+    "pil" runs the Pillow-exact integer path on the uint8 tensor itself.  `pil_dn` = PIL's HWC result (computed here with
+    PIL.Image.resize when not given).  Returns {"mae", "max", "variant", "proto" (HWC uint8 numpy), "pil"}."""
+    from interpolate_antialiasing_amd import _lib
+    from interpolate_antialiasing_amd import extension_interpolate as aa
+
+    fwd = {"bilinear": aa.linear_forward, "nearest": aa.nearest_forward, "bicubic": aa.cubic_forward}[mode]
+    if pil_dn is None:
+        from PIL import Image
+
+        resample = {"bilinear": Image.BILINEAR, "nearest": Image.BOX, "bicubic": Image.BICUBIC}[mode]
+        pil_dn = np.asarray(Image.fromarray(rgb).resize(tuple(size), resample=resample))
+    t_img = torch.from_numpy(np.ascontiguousarray(rgb.transpose(2, 0, 1))).cuda()  # uint8 CHW, channels-first like test.py:339
+    inv = [size[1], size[0]]
+    if uint8_mode == "harness":
+        out = fwd(t_img[None].float(), inv, False)
+        if mode == "bicubic":
+            out = torch.clamp(out, 0, 255)  # test.py:72
+        proto = out[0].byte()
+    else:
+        proto = fwd(t_img[None], inv, False, uint8_mode="pil")[0]
+    variant = _lib.last_variant()
+    proto = proto.permute(1, 2, 0).cpu().numpy()
+    err = np.abs(proto.astype(np.float64) - np.asarray(pil_dn).astype(np.float64))
+    return {"mae": float(err.mean()), "max": float(err.max()), "variant": variant, "proto": proto, "pil": np.asarray(pil_dn)}
+
+
 def main():
     ap = argparse.ArgumentParser("Antialiased interpolation on MI355X vs PIL")
     ap.add_argument("--mode", default="bilinear", choices=["bilinear", "nearest", "bicubic"])
@@ -53,25 +85,17 @@ def main():
     rows = []
     for size in sizes:
         inv = [size[1], size[0]]
-        pil_dn = torch.from_numpy(np.asarray(pil_img.resize(size, resample=resample)).copy().transpose(2, 0, 1)).cuda()
-        if args.uint8_mode == "harness":
-            out = fwd(t_img[None].float(), inv, False)
-            if args.mode == "bicubic":
-                out = torch.clamp(out, 0, 255)  # test.py:72
-            proto = out[0].byte()
-        else:
-            proto = fwd(t_img[None], inv, False, uint8_mode="pil")[0]
+        r = evaluate(rgb, size, args.mode, args.uint8_mode)
+        proto = torch.from_numpy(r["proto"]).permute(2, 0, 1).cuda()
+        pil_dn = torch.from_numpy(r["pil"].copy()).permute(2, 0, 1).cuda()
         ref = torch.nn.functional.interpolate(t_img[None].float(), size=inv, mode="nearest" if args.mode == "nearest" else args.mode,
                                               **({} if args.mode == "nearest" else {"align_corners": False}))[0].byte()
         mae_t = (pil_dn.float() - ref.float()).abs().mean().item()
         max_t = (pil_dn.float() - ref.float()).abs().max().item()
-        mae = (pil_dn.float() - proto.float()).abs().mean().item()
-        mx = (pil_dn.float() - proto.float()).abs().max().item()
-        print(f"size {size}: PyTorch(no AA) vs PIL: MAE {mae_t:.4f} Max {max_t:.0f} | ours[{_lib.last_variant()}] vs PIL: MAE {mae:.4f} Max {mx:.0f}")
-        if args.mode == "bilinear":
-            assert mae < 1.0 and mx < 1.0 + 1e-5  # test.py:370-372
-        elif args.mode == "bicubic":
-            assert mae < 1.0 and mx < 20.0       # test.py:377-379
+        mae, mx = r["mae"], r["max"]
+        print(f"size {size}: PyTorch(no AA) vs PIL: MAE {mae_t:.4f} Max {max_t:.0f} | ours[{r['variant']}] vs PIL: MAE {mae:.4f} Max {mx:.0f}")
+        if args.mode in THRESHOLDS:
+            assert mae < THRESHOLDS[args.mode][0] and mx < THRESHOLDS[args.mode][1]
         if args.out_dir:
             os.makedirs(args.out_dir, exist_ok=True)
             Image.fromarray(proto.permute(1, 2, 0).cpu().numpy()).save(
