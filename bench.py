@@ -29,27 +29,58 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 H_IN, W_IN, H_OUT, W_OUT, CH = 438, 906, 196, 320, 3
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ≈6290 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, which also quotes a 6.29 TB/s float4-copy ceiling)
+GUIDE_COPY_CEILING_GBS = 6290.0
+PMC_SUMMARIES = {  # dominant kernel -> committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes), newest first
+    "fused_u8_nhwc_pil_v3": ("r02_pmc_fused_v3.json", "r01_pmc_fused_v3.json"),
+    "fused_u8_nhwc_pil": ("r01_pmc_fused_v1.json",),
+}
 
 
 def pmc_traffic_bytes(variant: str, batch: int):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc, separate passes for
-    FETCH_SIZE and WRITE_SIZE, same command as this bench at --batch 1024).  Units: KiB.  gfx950 correction from
-    MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 128-byte requests of a 16-B-per-lane stream as 64 B -> x2; WRITE_SIZE is
-    exact.  Returns None when no summary matches the kernel that ran."""
-    name = {"fused_u8_nhwc_pil_v3": "r01_pmc_fused_v3.json", "fused_u8_nhwc_pil_v2": "r01_pmc_fused_v2.json",
-            "fused_u8_nhwc_pil": "r01_pmc_fused_v1.json"}.get(variant)
-    if name is None or batch != 1024:
-        return None
-    path = os.path.join(ROOT, "profiles", name)
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        fetch = d["FETCH_SIZE"]["avg_per_dispatch"]
-        write = d["WRITE_SIZE"]["avg_per_dispatch"]
-    except (OSError, KeyError, ValueError):
-        return None
-    return int((2.0 * fetch + write) * 1024)
+    """(HBM bytes per launch of the dominant kernel, source file) from the committed PMC summary (rocprofv3 --pmc, separate
+    passes for FETCH_SIZE and WRITE_SIZE, this bench's command at the summary's batch size).  Units: KiB.  gfx950 correction
+    from MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 128-byte requests of a 16-B-per-lane stream as 64 B -> x2; WRITE_SIZE is
+    exact.  The counters cannot be read from inside a process (they need rocprofv3 around it), so this is NOT live: the source
+    file is named in the bench line, and traffic scales with the batch (every image is fetched and written exactly once).
+    (None, None) when no summary matches the kernel that ran."""
+    for name in PMC_SUMMARIES.get(variant, ()):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            fetch = d["FETCH_SIZE"]["avg_per_dispatch"]
+            write = d["WRITE_SIZE"]["avg_per_dispatch"]
+            pmc_batch = int(d.get("batch", 1024))
+        except (OSError, KeyError, ValueError):
+            continue
+        return int((2.0 * fetch + write) * 1024 * batch / pmc_batch), f"profiles/{name} (batch {pmc_batch})"
+    return None, None
+
+
+def measure_copy_ceiling(dev, nbytes=2 << 30, reps=12):
+    """Attainable HBM ceiling on THIS box: a device copy of `nbytes` (read + write = 2 x nbytes of traffic, far
+    beyond the 256 MB Infinity Cache) by the library's 16-byte-per-lane grid-stride kernel (aa_probe_copy), HIP events on
+    the launch stream.  Returns GB/s of read + written bytes."""
+    from interpolate_antialiasing_amd import _lib
+
+    L = _lib.load()
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 256)
+    dst = torch.empty_like(src)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(3):
+        _lib.check(L.aa_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, stream), "aa_probe_copy")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        L.aa_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, stream)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    ok = bool(torch.equal(src[:1 << 20], dst[:1 << 20]) and torch.equal(src[-(1 << 20):], dst[-(1 << 20):]))
+    del src, dst
+    torch.cuda.empty_cache()
+    return (2.0 * nbytes / (ms * 1e-3) / 1e9) if ok else None
 
 
 def cpu_baseline(seconds: float = 12.0):
@@ -326,6 +357,9 @@ def main(argv=None):
         alg_bytes_img = CH * H_IN * W_IN + CH * H_OUT * W_OUT  # 1,378,644
         kern_ms = ev_ms / args.steps  # one hot-path pass per step
         achieved = alg_bytes_img * B / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic_bytes(variant, B)
+        del y
+        ceiling = measure_copy_ceiling(dev) if world == 1 else None  # (after the timed region; rank 0 at N = 1 only)
         out = {
             "metric": "Mpix/s (input pixels) antialiased bilinear 438x906->196x320, uint8 channels_last, PIL-exact",
             "value": round(mpix_s, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -338,9 +372,11 @@ def main(argv=None):
             "max_abs_err_vs_oracle": max_abs_e,
             "images_per_s": round(total_images / wall, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(variant, B),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": variant, "kernel_ms": round(kern_ms, 4), "alg_bytes_per_launch": alg_bytes_img * B,
-                         "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4)},
+                         "copy_ceiling_measured_GBs": None if ceiling is None else round(ceiling, 1),
+                         "frac_of_measured_copy_ceiling": None if ceiling is None else round(achieved / ceiling, 4),
+                         "frac_of_guide_copy_ceiling_6290": round(achieved / GUIDE_COPY_CEILING_GBS, 4)},
         }
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_configs(dev)

@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libaa_interp.so")
+# AA_INTERP_LIB: developer A/B runs of an alternative build of the SAME library (tools/ab_build.sh); never a fallback
+LIB_PATH = os.environ.get("AA_INTERP_LIB") or os.path.join(_HERE, "csrc", "libaa_interp.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "aa_interp.h")
 
 # enums (include/aa_interp.h)

@@ -42,6 +42,12 @@
 #define AA_V3_AUX 0  // cache-policy bits of the staging DMA (developer knob)
 #endif
 
+#ifndef AA_V3_UNALIGNED
+#define AA_V3_UNALIGNED 1  // window reads straight from the window's BYTE address (gfx950's LDS serves unaligned ds_read_b128 /
+                           // b64 / b32: the runtime runs the LDS in unaligned mode and hipcc itself emits such reads for
+                           // align-1 pointers): no dword-aligned over-read, no v_alignbyte realignment.  0: the aligned form.
+#endif
+
 // (shared by the per-channel-count translation units and the host-side dispatcher)
 struct FusedU8V3Params {
   int H, W, oH, oW;
@@ -245,6 +251,14 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       sa = lane_lds + (unsigned)(slot * p.seg_bytes) + (a_row & 15u);
       ra = sa & ~3u;
     }
+    if constexpr (AA_V3_UNALIGNED) {
+      typedef unsigned u32_any __attribute__((aligned(1)));
+      const __attribute__((address_space(3))) u32_any *ul = (const __attribute__((address_space(3))) u32_any *)(uintptr_t)sa;
+#pragma unroll
+      for (int k = 0; k < NV; k++) d[k] = ul[k];
+      d[ND - 1] = 0;
+      return sa;
+    }
     const __attribute__((address_space(3))) unsigned *al = (const __attribute__((address_space(3))) unsigned *)(uintptr_t)ra;
 #pragma unroll
     for (int k = 0; k < ND; k++) d[k] = al[k];
@@ -297,7 +311,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   // the window of the CURRENT row, realigned; consumes the LDS reads issued one row earlier
   auto realign = [&](const unsigned (&d)[ND], unsigned sa, unsigned (&v)[NV]) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sa);
+    for (int k = 0; k < NV; k++) v[k] = AA_V3_UNALIGNED ? d[k] : __builtin_amdgcn_alignbyte(d[k + 1], d[k], sa);
   };
   auto row_step = [&](const unsigned (&v)[NV], const Scatter &sc) {
     if (AA_V3_ABL == 6) return;
