@@ -58,29 +58,34 @@ def pmc_traffic_bytes(variant: str, batch: int):
     return None, None
 
 
-def measure_copy_ceiling(dev, nbytes=2 << 30, reps=12):
+def measure_copy_ceiling(dev, nbytes=2 << 30, reps=10):
     """Attainable HBM ceiling on THIS box: a device copy of `nbytes` (read + write = 2 x nbytes of traffic, far
-    beyond the 256 MB Infinity Cache) by the library's 16-byte-per-lane grid-stride kernel (aa_probe_copy), HIP events on
-    the launch stream.  Returns GB/s of read + written bytes."""
+    beyond the 256 MB Infinity Cache) by the library's 16-byte-per-lane copy kernels (aa_probe_copy, four forms), HIP events
+    on the launch stream.  Returns (best GB/s of read + written bytes, {form: GB/s})."""
     from interpolate_antialiasing_amd import _lib
 
     L = _lib.load()
     src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 256)
     dst = torch.empty_like(src)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    for _ in range(3):
-        _lib.check(L.aa_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, stream), "aa_probe_copy")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        L.aa_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, stream)
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    ok = bool(torch.equal(src[:1 << 20], dst[:1 << 20]) and torch.equal(src[-(1 << 20):], dst[-(1 << 20):]))
+    forms = {}
+    for form in range(4):
+        for _ in range(3):
+            _lib.check(L.aa_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, form, stream), "aa_probe_copy")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            L.aa_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, form, stream)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        ok = bool(torch.equal(src[:1 << 20], dst[:1 << 20]) and torch.equal(src[-(1 << 20):], dst[-(1 << 20):]))
+        if ok:
+            forms[form] = round(2.0 * nbytes / (ms * 1e-3) / 1e9, 1)
+        dst.zero_()
     del src, dst
     torch.cuda.empty_cache()
-    return (2.0 * nbytes / (ms * 1e-3) / 1e9) if ok else None
+    return (max(forms.values()) if forms else None), forms
 
 
 def cpu_baseline(seconds: float = 12.0):
@@ -359,7 +364,7 @@ def main(argv=None):
         achieved = alg_bytes_img * B / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic_bytes(variant, B)
         del y
-        ceiling = measure_copy_ceiling(dev) if world == 1 else None  # (after the timed region; rank 0 at N = 1 only)
+        ceiling, ceiling_forms = measure_copy_ceiling(dev) if world == 1 else (None, {})  # (after the timed region; N = 1 only)
         out = {
             "metric": "Mpix/s (input pixels) antialiased bilinear 438x906->196x320, uint8 channels_last, PIL-exact",
             "value": round(mpix_s, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -375,6 +380,7 @@ def main(argv=None):
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": variant, "kernel_ms": round(kern_ms, 4), "alg_bytes_per_launch": alg_bytes_img * B,
                          "copy_ceiling_measured_GBs": None if ceiling is None else round(ceiling, 1),
+                         "copy_ceiling_by_kernel_form": ceiling_forms,
                          "frac_of_measured_copy_ceiling": None if ceiling is None else round(achieved / ceiling, 4),
                          "frac_of_guide_copy_ceiling_6290": round(achieved / GUIDE_COPY_CEILING_GBS, 4)},
         }

@@ -179,9 +179,10 @@ size_t aa_workspace_bytes_bwd(int dtype, int layout, int64_t N, int64_t C, int64
 int aa_resample_axis_fwd(const void *in_dev, void *out_dev, int dtype, int64_t outer, int64_t in_size, int64_t inner,
                          const aa_axis *ax, aa_stream_t stream);
 
-/* Device-to-device copy of `bytes` bytes (16-byte vector loads/stores, grid-stride) enqueued on `stream`: the probe
- * bench.py times on the box to report the attainable HBM copy ceiling next to the 8 TB/s spec peak. */
-int aa_probe_copy(const void *src_dev, void *dst_dev, size_t bytes, aa_stream_t stream);
+/* Device-to-device copy of `bytes` bytes with 16-byte vector loads/stores, enqueued on `stream`: the probe bench.py times
+ * on the box to report the attainable HBM copy ceiling next to the 8 TB/s spec peak.  form 0: one element per
+ * thread; 1: grid-stride; 2: four elements per thread, loads in flight before the stores; 3: form 2, streaming (nt) policy. */
+int aa_probe_copy(const void *src_dev, void *dst_dev, size_t bytes, int form, aa_stream_t stream);
 
 /* Kernel selection, process-wide; returns the previous setting.  1 (default): fused single-launch kernels, newest
  * design first; 2: first-generation fused kernels only (A/B measurements); 0: none.

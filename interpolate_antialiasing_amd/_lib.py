@@ -101,7 +101,7 @@ def load() -> ctypes.CDLL:
     L.aa_resample_axis_fwd.argtypes = [vp, vp, i32, i64, i64, i64, ax, vp]
     L.aa_resample_axis_fwd.restype = i32
     L.aa_last_variant.restype = ctypes.c_char_p
-    L.aa_probe_copy.argtypes = [vp, vp, sz, vp]
+    L.aa_probe_copy.argtypes = [vp, vp, sz, i32, vp]
     L.aa_probe_copy.restype = i32
     L.aa_set_fused.argtypes = [i32]
     L.aa_set_fused.restype = i32

@@ -311,10 +311,10 @@ int aa_resample_axis_fwd(const void *in_dev, void *out_dev, int dtype, int64_t o
   return aa_launch_axis_fwd(in_dev, out_dev, dtype, outer, in_size, inner, *ax, (hipStream_t)stream);
 }
 
-int aa_probe_copy(const void *src_dev, void *dst_dev, size_t bytes, aa_stream_t stream) {
+int aa_probe_copy(const void *src_dev, void *dst_dev, size_t bytes, int form, aa_stream_t stream) {
   if (!src_dev || !dst_dev) return AA_ERR_NULL;
-  if ((((uintptr_t)src_dev | (uintptr_t)dst_dev) & 15) != 0) return AA_ERR_BAD_SHAPE;
-  return aa_launch_probe_copy(src_dev, dst_dev, bytes, (hipStream_t)stream);
+  if ((((uintptr_t)src_dev | (uintptr_t)dst_dev) & 15) != 0 || form < 0 || form > 3) return AA_ERR_BAD_SHAPE;
+  return aa_launch_probe_copy(src_dev, dst_dev, bytes, form, (hipStream_t)stream);
 }
 
 int aa_set_fused(int enabled) {

@@ -115,6 +115,6 @@ int aa_resident_blocks(K kern, int threads, size_t lds) {
   return nb;
 }
 
-int aa_launch_probe_copy(const void *src, void *dst, size_t bytes, hipStream_t stream);
+int aa_launch_probe_copy(const void *src, void *dst, size_t bytes, int form, hipStream_t stream);
 // scatter-add adjoint
 int aa_launch_bwd_atomic(const AAProblem &p);

@@ -1,18 +1,26 @@
 // aa_fused_float.hip — fused single-launch resample for fp32 NCHW tensors (BASELINE configs 0 and 2), reference arithmetic.
 //
-// Same wave-autonomous streaming design as aa_fused_u8_v3.hip, on floats:
-//   * one wave = one strip of <=64 output columns of one band of one (n, c) plane; the strips of a band share a
-//     workgroup only so that segment edges are served from L1/L2 (no barrier, no shared LDS);
-//   * input-row segments (the floats the strip's 64 windows cover) are staged into a private G-slot LDS ring by LDS-DMA
-//     (`buffer_load_dwordx4 ... lds`, range-checked), G-2 rows in flight behind a counted vmcnt;
-//   * horizontal pass: one lane per output pixel reads its taps from LDS (floats are dword aligned: no realignment) and
-//     accumulates exactly like the reference's inner loop (step_two_dot_two/aa_interpolation_impl.h:60-87): tap 0 first,
-//     then taps 1..xsize-1 in order, product and sum rounded separately (this file is built with -ffp-contract=off);
-//     taps at or beyond a lane's xsize are not added at all, so non-finite neighbours cannot leak in;
+// Second design (round 2).  The first one read every tap of every output from LDS with its own ds_read_b32: for the
+// bicubic 1024 -> 224 case (21 taps, window starts 32/7 dwords apart) that is 24 four-and-a-half-way bank-conflicted LDS
+// instructions per row, and its accumulators were indexed dynamically, which the compiler turned into scratch memory
+// (16-32 B per lane, rewritten on every row: the 3.4x WRITE_SIZE of the round-1 counters).  This one:
+//   * one wave = one strip of <= 64 output columns of one band of rows of one (n, c) plane, no barrier, no shared LDS;
+//   * input-row segments are staged into a private G-slot LDS ring by LDS-DMA (`buffer_load_dwordx4 ... lds`, range
+//     checked).  The DMA source starts at the segment's first float rounded down to a multiple of FOUR FLOATS OF THE ROW
+//     (dword-aligned in memory, not necessarily 16-byte aligned), so the LDS image of every row has the same phase: the
+//     float at row position x always lands at LDS offset 4 * (x - seg0), whatever W is;
+//   * horizontal pass: every lane reads its window with 16-byte ALIGNED ds_read_b128 (NQ of them: a third of a conflict
+//     group each, 4-6x fewer LDS cycles than per-tap reads).  The window therefore starts up to 3 floats before the
+//     lane's first tap; the lane's weights are loaded shifted by that amount once, at kernel start.  Positions outside
+//     the lane's own [first tap, last tap] are SKIPPED, not added with a zero weight: acc = in_window ? acc + d*w : acc
+//     with wave-level lane masks kept in scalar registers (one v_cndmask per position), so a non-finite neighbour never
+//     leaks in and the sum is the reference's, bit for bit (step_two_dot_two/aa_interpolation_impl.h:60-87: tap 0 first,
+//     then taps 1..xsize-1 in order, product and sum rounded separately; this file is built with -ffp-contract=off).
+//     The accumulator starts at -0.0f: (-0) + x == x exactly for every x, so the first tap is an assignment;
 //   * vertical pass in registers, scatter form: row r's result is multiplied by the weights it has in the outputs it
-//     feeds (scatter record of the H table) and added to their accumulators.  Rows arrive in increasing order, which
-//     IS the reference's tap order (:29-58), so the sums round identically;
-//   * a finished output row is one coalesced 256-byte store per wave.
+//     feeds (scatter record of the H table, one scalar load per row) and added to their accumulators, which are a
+//     compile-time-indexed register array.  Rows arrive in increasing order = the reference's tap order (:29-58);
+//   * a finished output row is one coalesced 256-byte store per wave (strips are 64 columns: whole 128-byte lines).
 // Roofline: HBM (fp32 config A: 5 514 576 B/image, config 2: 13 185 024 B/image; ~1.8-2.8 flop/B).
 
 #include <math.h>
@@ -24,6 +32,7 @@
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FusedF32Params {
   int H, W, oH, oW;
@@ -31,12 +40,12 @@ struct FusedF32Params {
   int ybands, nstrips, strips_per_block, strip_w;
   int nseg, seg_bytes;
   int sc_off;
-  int in_mis;
   unsigned long long plane_in_bytes, plane_out_bytes, total_in_bytes, total_out_bytes;
   long long n_groups;  // (plane, band) groups = planes * ybands
 };
 
 __device__ inline void wait_vmcnt_f(int n) {  // rounding n DOWN only waits longer
+  if (n >= 14) { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); return; }
   if (n >= 12) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); return; }
   if (n >= 8) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); return; }
   if (n >= 6) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); return; }
@@ -47,11 +56,21 @@ __device__ inline void wait_vmcnt_f(int n) {  // rounding n DOWN only waits long
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// TW: taps per lane (>= max xsize of the W table); G: staged rows (even); MAXC: outputs one input row can feed.
-template <int TW, int G, bool TWO_DMA, int MAXC>
+// dst = mask[lane] ? b : a, the lane mask in a scalar register pair (no per-row compare)
+__device__ inline float select_by_mask(float a, float b, unsigned long long mask) {
+  float d;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(mask));
+  return d;
+}
+
+// NQ: aligned 16-byte LDS reads per window (window positions TWP = 4*NQ >= max taps + 3); G: staged rows per wave;
+// NDMA: LDS-DMA instructions per staged row (segments of up to 64 * NDMA 16-byte pieces); MAXC: outputs one input row can feed.
+template <int NQ, int G, int NDMA, int MAXC>
 __global__ void __launch_bounds__(512)
 fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, const char *__restrict__ tab_w,
                       const char *__restrict__ tab_h, const FusedF32Params p) {
+  constexpr int TWP = 4 * NQ;
+  constexpr int TW = TWP - 3;  // taps a lane can hold
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
   const int lane = threadIdx.x & 63;
@@ -78,6 +97,7 @@ fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, con
   const int32_t *__restrict__ ysize_h = (const int32_t *)(tab_h + aa_table_xsize_off(p.oH));
   const int32_t *__restrict__ sc_rec = (const int32_t *)(tab_h + p.sc_off);
 
+  // input rows this band needs: [r_begin, r_stop)
   const int r_begin = __builtin_amdgcn_readfirstlane(ymin_h[oy0]);
   const int ylm = __builtin_amdgcn_readfirstlane(ymin_h[oy1 - 1]);
   const int yls = __builtin_amdgcn_readfirstlane(ysize_h[oy1 - 1]);
@@ -87,37 +107,36 @@ fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, con
 
   // ---- per-lane horizontal-pass state ------------------------------------------------------------------------
   const bool active = lane < bw;
-  const int ox = ox0 + (active ? lane : 0);
+  const int ox = ox0 + (active ? lane : 0);  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
   const int xm = xmin_w[ox];
   int xs = xsize_w[ox];
   xs = xs > 1 ? xs : 1;  // tap 0 is unconditional in the reference (s2.2:68-73)
+  xs = xs < TW ? xs : TW;
   int lead = xm + TW - p.W;  // right-align windows whose unused tail would leave the row
   lead = lead > 0 ? lead : 0;
-  const int start = xm - lead;
-  float wreg[TW];
+  const int start = xm - lead;            // row position of the lane's first readable float
+  const int astart = start & ~3;          // ... rounded down to the 16-byte grid of the row image
+  const int tap0 = (start & 3) + lead;    // window position of the reference's tap 0
+  float wreg[TWP];
+  unsigned long long inwin[TWP];  // lane masks (scalar registers): position q belongs to the lane's own taps
 #pragma unroll
-  for (int j = 0; j < TW; j++) {
-    const int src = j - lead;
-    wreg[j] = (src >= 0 && src < xs && src < p.ksize_w) ? kw[(size_t)ox * p.ksize_w + src] : 0.0f;
+  for (int q = 0; q < TWP; q++) {
+    const int j = q - tap0;
+    const bool mine = j >= 0 && j < xs;
+    wreg[q] = (mine && j < p.ksize_w) ? kw[(size_t)ox * p.ksize_w + j] : 0.0f;
+    inwin[q] = __ballot(mine);
   }
-  const int first_tap = lead;        // register index of the reference's tap 0
-  const int last_tap = lead + xs;    // one past its last tap
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const int seg_first = __builtin_amdgcn_readfirstlane(start * 4);
-  const int c_l = start * 4 - seg_first;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table loads done: from here on vmcnt counts DMAs and stores
+  const int seg0 = __builtin_amdgcn_readfirstlane(astart);  // lane 0 is always active and has the smallest start
+  const unsigned lane_lds = (unsigned)(wv * G * p.seg_bytes + (astart - seg0) * 4);  // multiple of 16
 
-  const unsigned long long img_off = (unsigned long long)p.in_mis + (unsigned long long)plane * p.plane_in_bytes;
-  const unsigned long long base_off = img_off & ~15ull;
-  unsigned long long remaining = p.total_in_bytes - base_off;
-  if (remaining > 0xFFFFFFFFull) remaining = 0xFFFFFFFFull;
+  const unsigned long long plane_off = (unsigned long long)plane * p.plane_in_bytes;
+  unsigned long long remaining = p.total_in_bytes - plane_off;
+  if (remaining > 0xFFFFFFFCull) remaining = 0xFFFFFFFCull;
   const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)in + base_off), 0, (unsigned)remaining, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)in + plane_off), 0, (unsigned)remaining, 0x00020000);
   const unsigned row_bytes = (unsigned)p.W * 4u;
   const int lds_base = wv * G * p.seg_bytes;
-  const unsigned lane_lds = (unsigned)(lds_base + c_l);
-  const bool dma_lane0 = lane < p.nseg;
-  const bool dma_lane1 = lane + 64 < p.nseg;
-  constexpr int dma_per_row = TWO_DMA ? 2 : 1;
   const unsigned voff = (unsigned)lane * 16u;
 
   const unsigned long long out_off = (unsigned long long)plane * p.plane_out_bytes;
@@ -128,82 +147,76 @@ fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, con
   const unsigned out_row_bytes = (unsigned)p.oW * 4u;
   const unsigned store_voff = (unsigned)(ox0 + lane) * 4u;
 
-  unsigned a = (unsigned)(img_off - base_off) + (unsigned)seg_first + (unsigned)r_begin * row_bytes;
+  // byte offset (from the plane) of the CURRENT row's segment
+  unsigned a = (unsigned)seg0 * 4u + (unsigned)r_begin * row_bytes;
 
+  // ---- vertical-pass state: MAXC accumulators, A[k] belongs to output row o_base + k -----------------------------
   float A[MAXC];
 #pragma unroll
-  for (int k = 0; k < MAXC; k++) A[k] = 0.0f;
+  for (int k2 = 0; k2 < MAXC; k2++) A[k2] = -0.0f;
   int o_base = oy0;
-  int done_row;
-  {
-    const int m = __builtin_amdgcn_readfirstlane(ymin_h[oy0]);
-    const int s = __builtin_amdgcn_readfirstlane(ysize_h[oy0]);
-    done_row = m + (s > 1 ? s : 1) - 1;
-  }
 
   auto dma = [&](unsigned a_row, int slot) {
-    const unsigned soff = a_row & ~15u;
     const int dst = lds_base + slot * p.seg_bytes;
-    if (dma_lane0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, soff, 0, 0);
-    if constexpr (TWO_DMA) {
-      if (dma_lane1)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst + 1024), 16, voff + 1024, soff, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NDMA; i++) {
+      if (lane + 64 * i < p.nseg)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst + 1024 * i), 16, voff + 1024u * i, a_row, 0, 0);
     }
   };
-  struct Scatter { int first; int cnt; float w[MAXC]; };
-  auto load_scatter = [&](int r) -> Scatter {
+  struct Scatter { int first; int cc; float w[MAXC]; };
+  auto load_scatter = [&](int r) -> Scatter {  // one 32-byte record: {first, count | completes << 16, w[6]}; r == H: sentinel
     Scatter s;
-    const int rr = r < p.H ? r : p.H - 1;
-    const int32_t *rec = sc_rec + (size_t)rr * 8;
+    const int32_t *rec = (const int32_t *)((const char *)sc_rec + (unsigned)r * 32u);
     s.first = __builtin_amdgcn_readfirstlane(rec[0]);
-    s.cnt = __builtin_amdgcn_readfirstlane(rec[1]) & 0xFFFF;  // (high half: outputs completing at this row)
+    s.cc = __builtin_amdgcn_readfirstlane(rec[1]);
 #pragma unroll
-    for (int k = 0; k < MAXC; k++) s.w[k] = __int_as_float(__builtin_amdgcn_readfirstlane(rec[2 + k]));
+    for (int k2 = 0; k2 < MAXC; k2++) s.w[k2] = __int_as_float(__builtin_amdgcn_readfirstlane(rec[2 + k2]));
     return s;
   };
-  auto emit = [&](int oy) {
+  auto emit = [&](int oy) {  // accumulator 0 is complete: store it, slide the others down
     if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(A[0]), orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
 #pragma unroll
-    for (int k = 0; k + 1 < MAXC; k++) A[k] = A[k + 1];
-    A[MAXC - 1] = 0.0f;
+    for (int k2 = 0; k2 + 1 < MAXC; k2++) A[k2] = A[k2 + 1];
+    A[MAXC - 1] = -0.0f;
   };
-  // one input row: taps from LDS, reference-order accumulation, scatter into the open outputs
-  auto row_step = [&](unsigned a_row, int slot, int r, const Scatter &sc) {
-    const unsigned sa = lane_lds + (unsigned)(slot * p.seg_bytes) + (a_row & 15u);  // multiple of 4
-    const __attribute__((address_space(3))) float *src = (const __attribute__((address_space(3))) float *)(uintptr_t)sa;
-    float d[TW];
+  // one input row: window from LDS, reference-order accumulation over the lane's own taps, scatter into the open outputs
+  auto row_step = [&](int slot, const Scatter &sc) {
+    const __attribute__((address_space(3))) f32x4 *src =
+        (const __attribute__((address_space(3))) f32x4 *)(uintptr_t)(lane_lds + (unsigned)(slot * p.seg_bytes));
+    f32x4 d[NQ];
 #pragma unroll
-    for (int j = 0; j < TW; j++) d[j] = src[j];
-    // acc = t0*w0; acc += tj*wj for the lane's own taps only (registers [first_tap, last_tap))
-    float acc = 0.0f;
+    for (int q = 0; q < NQ; q++) d[q] = src[q];
+    float acc = -0.0f;
 #pragma unroll
-    for (int j = 0; j < TW; j++) {
-      const float prod = d[j] * wreg[j];
+    for (int q = 0; q < TWP; q++) {
+      const float prod = d[q >> 2][q & 3] * wreg[q];
       const float sum = acc + prod;
-      acc = (j == first_tap) ? prod : ((j > first_tap && j < last_tap) ? sum : acc);
+      acc = select_by_mask(acc, sum, inwin[q]);
     }
-    const int idx0 = sc.first - o_base;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the window is in registers: the caller may refill the slot)
+    const int cnt = sc.cc & 0xFFFF;
+    const int idx0 = sc.first - o_base;  // 0 in steady state; negative while the band's first rows still feed outputs
+                                         // of the previous band
+    if (__builtin_expect(idx0 == 0, 1)) {
 #pragma unroll
-    for (int k = 0; k < MAXC; k++) {
-      if (k >= sc.cnt) break;  // wave-uniform: only the outputs this row really belongs to
-      const int slot_k = idx0 + k;
+      for (int k2 = 0; k2 < MAXC; k2++)
+        if (k2 < cnt) A[k2] = A[k2] + acc * sc.w[k2];  // wave-uniform: only the outputs whose window holds this row
+    } else if (idx0 < 0 && idx0 > -MAXC) {
 #pragma unroll
-      for (int s = 0; s < MAXC; s++) {
-        if (slot_k == s) {
-          // an output's first tap lands on the initial 0: 0 + x == x exactly (the reference assigns tap 0), so the
-          // running sums round identically from there on
-          A[s] = A[s] + acc * sc.w[k];
+      for (int s = 1; s < MAXC; s++) {
+        if (idx0 == -s) {
+#pragma unroll
+          for (int k2 = s; k2 < MAXC; k2++)
+            if (k2 < cnt) A[k2 - s] = A[k2 - s] + acc * sc.w[k2];
         }
       }
     }
-    while (r == done_row && o_base < oy1) {
+    const int sc_end = sc.first + (sc.cc >> 16);     // outputs [first, sc_end) take their LAST row here
+    const int e_end = sc_end < oy1 ? sc_end : oy1;  // (outputs below o_base belong to the previous band)
+    while (o_base < e_end) {
       emit(o_base);
       o_base++;
-      if (o_base < oy1) {
-        const int m = __builtin_amdgcn_readfirstlane(ymin_h[o_base]);
-        const int s = __builtin_amdgcn_readfirstlane(ysize_h[o_base]);
-        done_row = m + (s > 1 ? s : 1) - 1;
-      }
     }
   };
 
@@ -215,11 +228,10 @@ fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, con
     if (x0 + 2 * G <= n_rows) {
 #pragma unroll
       for (int i = 0; i < G; i++) {
-        // row x must have landed: rows x+1 .. x+G-1 were issued after it
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_row * (G - 1)) : "memory");
+        // row x must have landed: rows x+1 .. x+G-1 (and any output stores) were issued after it
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (G - 1)) : "memory");
         const Scatter sc = load_scatter(r);
-        row_step(a, i, r, sc);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the taps are in registers: the slot may be refilled
+        row_step(i, sc);
         dma(a + (unsigned)G * row_bytes, i);
         a += row_bytes;
         r++;
@@ -230,10 +242,9 @@ fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, con
         if (x >= n_rows) break;
         int younger = n_rows - 1 - x;
         younger = younger < G - 1 ? younger : G - 1;
-        wait_vmcnt_f(younger * dma_per_row);
+        wait_vmcnt_f(younger * NDMA);
         const Scatter sc = load_scatter(r);
-        row_step(a, i, r, sc);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        row_step(i, sc);
         if (x + G < n_rows) dma(a + (unsigned)G * row_bytes, i);
         a += row_bytes;
         r++;
@@ -263,9 +274,10 @@ int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int64_t H, i
   return (int)ybands;
 }
 
-template <int TW, int G, bool TWO, int MAXC>
-int launch_k(FusedF32Params p, const AAProblem &q, size_t lds) {
-  auto kern = fused_f32_nchw_kernel<TW, G, TWO, MAXC>;
+template <int NQ, int G, int NDMA, int MAXC>
+int launch_k(FusedF32Params p, const AAProblem &q) {
+  auto kern = fused_f32_nchw_kernel<NQ, G, NDMA, MAXC>;
+  const size_t lds = (size_t)G * p.seg_bytes;  // per strip (wave)
   auto resident = [&](int s) {  // workgroups of s strips a CU holds (-1: their rings do not fit a workgroup's LDS)
     if (lds * s > 64 * 1024) return -1;  // (never for s == 1: a strip's ring is at most 16 KiB)
     int nb = aa_resident_blocks(kern, 64 * s, lds * s);
@@ -278,8 +290,11 @@ int launch_k(FusedF32Params p, const AAProblem &q, size_t lds) {
   };
   // strips of a band share a workgroup unless single-strip workgroups put more waves on a CU (see aa_fused_u8_v3_impl.h)
   int spb = p.strips_per_block;
-  if (spb > 1 && resident(1) > 0 && (resident(spb) < 0 || resident(1) > resident(spb) * spb)) spb = 1;
-  if (resident(spb) < 0) return 0;
+  if (spb > 1 && (resident(spb) < 0 || resident(1) > resident(spb) * spb)) spb = 1;
+  if (const char *e = getenv("AA_F32_SPB")) {  // experiment knob
+    const int v = atoi(e);
+    if (v >= 1 && v <= 8 && resident(v) > 0) spb = v;
+  }
   p.strips_per_block = spb;
   const int sgroups = (p.nstrips + spb - 1) / spb;
   const size_t lds_blk = lds * spb;
@@ -289,26 +304,48 @@ int launch_k(FusedF32Params p, const AAProblem &q, size_t lds) {
   p.n_groups = planes * (int64_t)p.ybands;
   const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, (const float *)((const uint8_t *)q.in - p.in_mis),
-                     (float *)q.out, (const char *)q.aw.table_dev, (const char *)q.ah.table_dev, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, (const float *)q.in, (float *)q.out,
+                     (const char *)q.aw.table_dev, (const char *)q.ah.table_dev, p);
   AA_HIP_CHECK_LAUNCH();
   return 1;
 }
 
-template <int TW, int G>
-int launch_m(int maxc, const FusedF32Params &p, const AAProblem &q, size_t lds) {
-  const bool two = p.nseg > 64;
-  if (maxc <= 2) return two ? launch_k<TW, G, true, 2>(p, q, lds) : launch_k<TW, G, false, 2>(p, q, lds);
-  if (maxc <= 3) return two ? launch_k<TW, G, true, 3>(p, q, lds) : launch_k<TW, G, false, 3>(p, q, lds);
-  if (maxc <= 4) return two ? launch_k<TW, G, true, 4>(p, q, lds) : launch_k<TW, G, false, 4>(p, q, lds);
-  return two ? launch_k<TW, G, true, 6>(p, q, lds) : launch_k<TW, G, false, 6>(p, q, lds);
+template <int NQ, int G, int NDMA>
+int launch_m(int maxc, const FusedF32Params &p, const AAProblem &q) {
+  if (maxc <= 2) return launch_k<NQ, G, NDMA, 2>(p, q);
+  if (maxc <= 3) return launch_k<NQ, G, NDMA, 3>(p, q);
+  if (maxc <= 4) return launch_k<NQ, G, NDMA, 4>(p, q);
+  return launch_k<NQ, G, NDMA, 6>(p, q);
 }
 
-int round_tw_f(int taps) {
-  const int opts[] = {2, 4, 8, 12, 16, 24};
+// staged rows per wave: 8 while a row segment is one DMA instruction (<= 1 KiB), 4 beyond (rings stay <= 8 KiB per wave)
+template <int NQ>
+int launch_q(int maxc, const FusedF32Params &p, const AAProblem &q) {
+  return p.nseg <= 64 ? launch_m<NQ, 8, 1>(maxc, p, q) : launch_m<NQ, 4, 2>(maxc, p, q);
+}
+
+// window quads for a table whose widest window has `taps` taps: 4 * NQ - 3 >= taps
+int quads_for(int taps) {
+  const int opts[] = {2, 3, 4, 5, 7};
   for (int o : opts)
-    if (taps <= o) return o;
+    if (taps <= 4 * o - 3) return o;
   return 0;
+}
+
+struct F32Geometry { int nq, nstrips, strip_w, nseg; };
+
+bool f32_geometry(int64_t W, const aa_axis &aw, F32Geometry *g) {
+  const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
+  g->nq = quads_for(taps_w);
+  if (g->nq == 0 || W < 4 * g->nq - 3) return false;
+  if (aw.span64p1 <= 0) return false;
+  const int64_t oW = aw.out_size;
+  g->strip_w = 64;  // whole 128-byte lines per stored row piece (the last strip may be shorter)
+  g->nstrips = (int)((oW + 63) / 64);
+  // floats a strip's windows cover: the spread of 64 window starts (+3: the first one rounded down to a multiple of 4)
+  // + one window
+  g->nseg = (aw.span64p1 + 3 + 4 * g->nq + 3) / 4;
+  return g->nseg <= 128;
 }
 
 }  // namespace
@@ -319,52 +356,45 @@ bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t N, int64_t C,
   if (!ah || !aw || ah->kind != AA_TABLE_F32 || aw->kind != AA_TABLE_F32) return false;
   if (ah->scatter_off <= 0 || ah->scatter_max <= 0 || ah->scatter_max > 6) return false;
   if (H < ah->out_size) return false;
-  const int taps_w = aw->max_taps > 0 ? aw->max_taps : aw->ksize;
-  const int tw = round_tw_f(taps_w);
-  if (tw == 0 || W < tw) return false;
+  F32Geometry g;
+  if (!f32_geometry(W, *aw, &g)) return false;
   if ((uint64_t)H * W * 4 > 0xFFFFFFF0ull) return false;
-  const int span_px = aa_strip_span_px(*aw, tw);
-  if (span_px < 0 || (span_px * 4 + 15 + 15) / 16 > 128) return false;
   if ((uint64_t)ah->out_size * aw->out_size * 4 > 0xFFFFFFF0ull) return false;
-  if (!aa_grid_fits(N * C * ((aw->out_size + 63) / 64 + 1))) return false;
+  if (!aa_grid_fits(N * C * g.nstrips)) return false;
   return true;
 }
 
 int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
   if (!aa_fused_float_nchw_applicable(q.dtype, q.layout, q.N, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
   if (((uintptr_t)q.out & 3) != 0 || ((uintptr_t)q.in & 3) != 0) return 0;
-  const int taps_w = q.aw.max_taps > 0 ? q.aw.max_taps : q.aw.ksize;
-  const int tw = round_tw_f(taps_w);
+  F32Geometry g;
+  f32_geometry(q.W, q.aw, &g);
 
   FusedF32Params p;
   p.H = (int)q.H; p.W = (int)q.W; p.oH = (int)q.oH; p.oW = (int)q.oW;
   p.ksize_w = q.aw.ksize; p.ksize_h = q.ah.ksize;
   p.plane_in_bytes = (unsigned long long)q.H * q.W * 4;
   p.plane_out_bytes = (unsigned long long)q.oH * q.oW * 4;
-  p.in_mis = (int)((uintptr_t)q.in & 15);
-  p.total_in_bytes = p.plane_in_bytes * (unsigned long long)(q.N * q.C) + (unsigned long long)p.in_mis;
+  p.total_in_bytes = p.plane_in_bytes * (unsigned long long)(q.N * q.C);
   p.total_out_bytes = p.plane_out_bytes * (unsigned long long)(q.N * q.C);
   p.sc_off = q.ah.scatter_off;
-  p.nstrips = (int)((q.oW + 63) / 64);
-  p.strip_w = (int)((q.oW + p.nstrips - 1) / p.nstrips);
-  p.nstrips = (int)((q.oW + p.strip_w - 1) / p.strip_w);
+  p.nstrips = g.nstrips;
+  p.strip_w = g.strip_w;
   p.strips_per_block = p.nstrips <= 8 ? p.nstrips : 4;
-  const int span_px = aa_strip_span_px(q.aw, tw);
-  p.nseg = (span_px * 4 + 15 + 15) / 16;
+  p.nseg = g.nseg;
   p.seg_bytes = p.nseg * 16;
   p.ybands = 1;
+  p.n_groups = 0;
 
   int rc = 0;
   const int mc = q.ah.scatter_max;
-  // G (rows in flight) shrinks as segments grow so that a workgroup's stage rings stay within 64 KiB
-  const size_t lds8 = (size_t)8 * p.seg_bytes, lds4 = (size_t)4 * p.seg_bytes;
-  const bool g8 = lds8 * p.strips_per_block <= 32 * 1024;
-  if (tw <= 2) rc = g8 ? launch_m<2, 8>(mc, p, q, lds8) : launch_m<2, 4>(mc, p, q, lds4);
-  else if (tw <= 4) rc = g8 ? launch_m<4, 8>(mc, p, q, lds8) : launch_m<4, 4>(mc, p, q, lds4);
-  else if (tw <= 8) rc = g8 ? launch_m<8, 8>(mc, p, q, lds8) : launch_m<8, 4>(mc, p, q, lds4);
-  else if (tw <= 12) rc = g8 ? launch_m<12, 8>(mc, p, q, lds8) : launch_m<12, 4>(mc, p, q, lds4);
-  else if (tw <= 16) rc = g8 ? launch_m<16, 8>(mc, p, q, lds8) : launch_m<16, 4>(mc, p, q, lds4);
-  else rc = g8 ? launch_m<24, 8>(mc, p, q, lds8) : launch_m<24, 4>(mc, p, q, lds4);
+  switch (g.nq) {
+    case 2: rc = launch_q<2>(mc, p, q); break;
+    case 3: rc = launch_q<3>(mc, p, q); break;
+    case 4: rc = launch_q<4>(mc, p, q); break;
+    case 5: rc = launch_q<5>(mc, p, q); break;
+    default: rc = launch_q<7>(mc, p, q); break;
+  }
   if (rc == 1) *variant = "fused_f32_nchw";
   return rc;
 }

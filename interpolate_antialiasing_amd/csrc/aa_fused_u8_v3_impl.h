@@ -43,9 +43,10 @@
 #endif
 
 #ifndef AA_V3_UNALIGNED
-#define AA_V3_UNALIGNED 1  // window reads straight from the window's BYTE address (gfx950's LDS serves unaligned ds_read_b128 /
-                           // b64 / b32: the runtime runs the LDS in unaligned mode and hipcc itself emits such reads for
-                           // align-1 pointers): no dword-aligned over-read, no v_alignbyte realignment.  0: the aligned form.
+#define AA_V3_UNALIGNED 0  // 1: window reads straight from the window's BYTE address (gfx950's LDS does serve unaligned
+                           // ds_read_b32/b64, and hipcc emits them for align-1 pointers), saving the 5 v_alignbyte per row.
+                           // MEASURED on MI355X (profiles/r02_unaligned_lds_reads.txt): results identical, kernel 3.6x
+                           // SLOWER (1.02 ms vs 0.283 ms per 1024 images): a misaligned LDS dword is not a one-pass access.
 #endif
 
 // (shared by the per-channel-count translation units and the host-side dispatcher)

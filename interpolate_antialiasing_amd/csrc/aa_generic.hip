@@ -210,19 +210,58 @@ int aa_launch_axis_fwd(const void *in, void *out, int dtype, int64_t outer, int6
 
 // ---- HBM copy-ceiling probe (bench.py: "measure the attainable ceiling on the box") -----------------------
 namespace {
-__global__ void __launch_bounds__(256) probe_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// form 0: one 16-byte element per thread; form 1: grid-stride over a grid of 32 workgroups per CU; form 2: four elements per
+// thread, each wave-instruction a contiguous 1 KiB, all four loads in flight before the first store; form 3: form 2 with
+// the streaming (nt) policy on loads and stores.  bench.py reports the best of them.
+template <int FORM>
+__global__ void __launch_bounds__(256) probe_copy_kernel(const u32x4_t *__restrict__ src, u32x4_t *__restrict__ dst, size_t n16) {
+  if constexpr (FORM == 0) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+  } else if constexpr (FORM == 1) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+  } else {
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    u32x4_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const size_t i = base + 256 * k;
+      if (i < n16) v[k] = FORM == 3 ? __builtin_nontemporal_load(&src[i]) : src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const size_t i = base + 256 * k;
+      if (i < n16) {
+        if (FORM == 3) __builtin_nontemporal_store(v[k], &dst[i]);
+        else dst[i] = v[k];
+      }
+    }
+  }
 }
 }  // namespace
 
-int aa_launch_probe_copy(const void *src, void *dst, size_t bytes, hipStream_t stream) {
+int aa_launch_probe_copy(const void *src, void *dst, size_t bytes, int form, hipStream_t stream) {
   const size_t n16 = bytes / 16;
   if (n16 == 0) return AA_OK;
-  size_t blocks = (n16 + 255) / 256;
-  const size_t cap = (size_t)aa_device_cu_count() * 32;  // 8 waves per SIMD's worth of 256-thread workgroups, grid-stride beyond
-  if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4 *)src, (uint4 *)dst, n16);
+  const u32x4_t *s = (const u32x4_t *)src;
+  u32x4_t *d = (u32x4_t *)dst;
+  if (form == 1) {
+    size_t blocks = (n16 + 255) / 256;
+    const size_t cap = (size_t)aa_device_cu_count() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(probe_copy_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
+  } else if (form == 0) {
+    const size_t blocks = (n16 + 255) / 256;
+    if (blocks > 0x7FFFFFFF) return AA_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(probe_copy_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
+  } else {
+    const size_t blocks = (n16 + 1023) / 1024;
+    if (blocks > 0x7FFFFFFF) return AA_ERR_BAD_SHAPE;
+    if (form == 2) hipLaunchKernelGGL(probe_copy_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
+    else hipLaunchKernelGGL(probe_copy_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
+  }
   AA_HIP_CHECK_LAUNCH();
   return AA_OK;
 }
