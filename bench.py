@@ -190,6 +190,9 @@ def secondary_configs(dev):
         1024 * 3 * (906 * 438 + 320 * 196))
     add("configs[3] shard in the reference harness's uint8 semantics (float(), fp32 op, truncating byte())",
         lambda: aa.linear_forward(x, [320, 196], uint8_mode="harness"), 1024 * 3 * (906 * 438 + 320 * 196))
+    add("decode-adjacent: uint8 HWC [1024,906,438,3] -> float32 NCHW [1024,3,320,196] in one launch (+ mean/std)",
+        lambda: aa.linear_forward(x, [320, 196], out_dtype=torch.float32, out_format="nchw", mean=[123.675, 116.28, 103.53],
+                                  std=[58.395, 57.12, 57.375]), 1024 * 3 * (906 * 438 + 4 * 320 * 196))
     x = x.contiguous()
     add("uint8 NCHW (planar) [1024,3,906,438]->[320,196] bilinear", lambda: aa.linear_forward(x, [320, 196]),
         1024 * 3 * (906 * 438 + 320 * 196))
@@ -197,6 +200,8 @@ def secondary_configs(dev):
     g = torch.randn(256, 3, 196, 320, device=dev)
     add("configs[4] batched: backward fp32 grad [256,3,196,320]->[256,3,438,906], gather form (true adjoint)",
         lambda: aa.linear_backward(g, [196, 320], [256, 3, 438, 906]), 256 * 3 * 4 * (438 * 906 + 196 * 320))
+    add("configs[4] batched, scatter-add ATOMICS form (API parity; the gather form above is the product path)",
+        lambda: aa.linear_backward(g, [196, 320], [256, 3, 438, 906], atomic=True), 256 * 3 * 4 * (438 * 906 + 196 * 320))
     g1 = torch.randn(1, 3, 196, 320, device=dev)
     add("configs[4] as written: backward fp32 grad [1,3,196,320]->[1,3,438,906], gather form (latency)",
         lambda: aa.linear_backward(g1, [196, 320], [1, 3, 438, 906]), 3 * 4 * (438 * 906 + 196 * 320))

@@ -158,6 +158,24 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
                     int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
                     aa_stream_t stream);
 
+/* Decode-adjacent forward: uint8 image in, float32 tensor out, ONE launch.  Replaces what the reference's harness
+ * does around the op on the CPU — np.asarray(pil) -> transpose(2,0,1) -> .float() -> op (test.py:337-339,55; README.md:416
+ * prices those conversions at 0.33 of 2.27 ms) — and, optionally, the per-channel normalisation that follows in a data
+ * loader.  out = op(float(in)) in the reference's fp32 arithmetic (AA_TABLE_F32 tables; bit-identical to aa_resample_fwd on
+ * the converted tensor), written in cv->out_layout, which may differ from the input's; with cv->normalize,
+ * out = (out - mean[c]) / std[c] in fp32 (C <= 4).  in_dev [N,C,H,W] uint8 in `layout`; out_dev [N,C,oH,oW] float32. */
+typedef struct aa_convert {
+  int32_t out_layout; /* aa_layout of the float32 output */
+  int32_t normalize;  /* 0: raw op result */
+  float mean[4];
+  float std[4];
+} aa_convert;
+size_t aa_workspace_bytes_u8_to_f32(int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
+                                    const aa_convert *cv);
+int aa_resample_fwd_u8_to_f32(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int layout,
+                              int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
+                              const aa_convert *cv, aa_stream_t stream);
+
 /* Backward (true adjoint): grad_in[N,C,H,W] = H^T V^T grad_out[N,C,oH,oW], F32/F64 only.  Replaces
  * ti_upsample_bilinear2d_backward_cpu (s2.2/aa_interpolation_backward_impl.h:185-219) in API shape.
  * tr_h / tr_w are TRANSPOSED tables from aa_table_transpose (gather form: deterministic, no atomics, no zero fill). */

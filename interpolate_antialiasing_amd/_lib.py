@@ -27,7 +27,7 @@ EXPORTS = (
     "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build_bytes", "aa_table_build",
     "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_workspace_bytes", "aa_resample_fwd",
     "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_resample_axis_fwd", "aa_set_fused",
-    "aa_last_variant", "aa_probe_copy",
+    "aa_last_variant", "aa_probe_copy", "aa_workspace_bytes_u8_to_f32", "aa_resample_fwd_u8_to_f32",
 )
 
 
@@ -47,6 +47,11 @@ class Axis(ctypes.Structure):
         ("scatter_off", ctypes.c_int32), ("scatter_ksize", ctypes.c_int32), ("scatter_max", ctypes.c_int32),
         ("span64p1", ctypes.c_int32),
     ]
+
+
+class Convert(ctypes.Structure):
+    _fields_ = [("out_layout", ctypes.c_int32), ("normalize", ctypes.c_int32), ("mean", ctypes.c_float * 4),
+                ("std", ctypes.c_float * 4)]
 
 
 class AAInterpError(RuntimeError):
@@ -101,6 +106,11 @@ def load() -> ctypes.CDLL:
     L.aa_resample_axis_fwd.argtypes = [vp, vp, i32, i64, i64, i64, ax, vp]
     L.aa_resample_axis_fwd.restype = i32
     L.aa_last_variant.restype = ctypes.c_char_p
+    cvp = ctypes.POINTER(Convert)
+    L.aa_workspace_bytes_u8_to_f32.argtypes = [i32, i64, i64, i64, i64, ax, ax, cvp]
+    L.aa_workspace_bytes_u8_to_f32.restype = sz
+    L.aa_resample_fwd_u8_to_f32.argtypes = [vp, vp, vp, sz, i32, i64, i64, i64, i64, ax, ax, cvp, vp]
+    L.aa_resample_fwd_u8_to_f32.restype = i32
     L.aa_probe_copy.argtypes = [vp, vp, sz, i32, vp]
     L.aa_probe_copy.restype = i32
     L.aa_set_fused.argtypes = [i32]

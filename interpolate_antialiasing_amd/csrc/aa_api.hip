@@ -250,6 +250,61 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
   return rc;
 }
 
+static int fill_convert(AAProblem &p, const aa_convert *cv, int64_t C) {
+  if (!cv) return AA_ERR_NULL;
+  if (cv->out_layout != AA_NCHW && cv->out_layout != AA_NHWC) return AA_ERR_BAD_LAYOUT;
+  if (cv->normalize && C > 4) return AA_ERR_BAD_SHAPE;
+  p.out_f32 = 1;
+  p.out_layout = cv->out_layout;
+  p.normalize = cv->normalize ? 1 : 0;
+  for (int i = 0; i < 4; i++) { p.mean[i] = cv->mean[i]; p.std[i] = cv->std[i]; }
+  return AA_OK;
+}
+
+size_t aa_workspace_bytes_u8_to_f32(int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
+                                    const aa_convert *cv) {
+  if (!ax_h || !ax_w || !cv || N <= 0) return 0;
+  if (g_fused_enabled == 1 && aa_fused_u8_v3_applicable(AA_U8, layout, N, C, H, W, ax_h, ax_w, 1, cv->out_layout)) return 0;
+  return aa_generic_workspace_bytes(AA_U8, AA_TABLE_F32, N, C, H, ax_w->out_size);
+}
+
+int aa_resample_fwd_u8_to_f32(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int layout,
+                              int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
+                              const aa_convert *cv, aa_stream_t stream) {
+  if (layout != AA_NCHW && layout != AA_NHWC) return AA_ERR_BAD_LAYOUT;
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0) return AA_ERR_BAD_SHAPE;
+  int rc = check_axis(ax_h, H);
+  if (rc != AA_OK) return rc;
+  rc = check_axis(ax_w, W);
+  if (rc != AA_OK) return rc;
+  if (ax_h->kind != AA_TABLE_F32 || ax_w->kind != AA_TABLE_F32) return AA_ERR_BAD_DTYPE;  // float output = float arithmetic
+  AAProblem p;
+  rc = fill_convert(p, cv, C);
+  if (rc != AA_OK) return rc;
+  if (N == 0) {
+    g_last_variant = "empty";
+    return AA_OK;
+  }
+  if (!in_dev || !out_dev) return AA_ERR_NULL;
+  p.in = in_dev; p.out = out_dev; p.ws = workspace_dev; p.ws_bytes = workspace_bytes;
+  p.dtype = AA_U8; p.layout = layout;
+  p.N = N; p.C = C; p.H = H; p.W = W; p.oH = ax_h->out_size; p.oW = ax_w->out_size;
+  p.ah = *ax_h; p.aw = *ax_w;
+  p.stream = (hipStream_t)stream;
+  const char *variant = "none";
+  rc = g_fused_enabled == 1 ? aa_try_fused_u8_nhwc_v3(p, &variant) : 0;
+  if (rc < 0) return rc;
+  if (rc == 1) {
+    g_last_variant = variant;
+    return AA_OK;
+  }
+  const size_t need = aa_generic_workspace_bytes(AA_U8, AA_TABLE_F32, N, C, H, p.oW);
+  if (!workspace_dev || workspace_bytes < need) return AA_ERR_WORKSPACE;
+  rc = aa_launch_generic_convert(p, &variant);
+  if (rc == AA_OK) g_last_variant = variant;
+  return rc;
+}
+
 size_t aa_workspace_bytes_bwd(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, int64_t oH, int64_t oW) {
   (void)layout; (void)H; (void)oW;
   if (N <= 0) return 0;

@@ -65,6 +65,13 @@ struct AAProblem {
   int64_t N, C, H, W, oH, oW;
   aa_axis ah, aw;
   hipStream_t stream;
+  // decode-adjacent conversion (aa_resample_fwd_u8_to_f32): uint8 in, float32 out, optional layout change and per-channel
+  // (v - mean) / std.  out_f32 == 0: the output has the input's dtype and layout.
+  int out_f32 = 0;
+  int out_layout = AA_NCHW;
+  int normalize = 0;
+  float mean[4] = {0.f, 0.f, 0.f, 0.f};
+  float std[4] = {1.f, 1.f, 1.f, 1.f};
 };
 
 // generic two-launch separable path (always available); returns variant name through *variant
@@ -72,6 +79,7 @@ int aa_launch_generic_fwd(const AAProblem &p, const char **variant);
 int aa_launch_axis_fwd(const void *in, void *out, int dtype, int64_t outer, int64_t in_size, int64_t inner, const aa_axis &ax,
                        hipStream_t stream);
 size_t aa_generic_workspace_bytes(int dtype, int kind_w, int64_t N, int64_t C, int64_t H, int64_t oW);
+int aa_launch_generic_convert(const AAProblem &p, const char **variant);  // u8 -> f32 (+ layout, normalisation), two launches
 // fused single-launch paths; return 1 when they took the problem, 0 when not applicable, <0 on error
 int aa_try_fused_u8_nhwc(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw(const AAProblem &p, const char **variant);
@@ -79,7 +87,8 @@ int aa_try_fused_float_nchw_up(const AAProblem &p, const char **variant);  // H 
 int aa_try_fused_u8_nhwc_v3(const AAProblem &p, const char **variant);  // LDS-DMA staged, wave-autonomous, V pass in registers
 // The *_applicable predicates hold EVERY reason a fused path can decline that does not depend on the pointers (shape, LDS
 // size, grid size, dispatch widths): aa_workspace_bytes() answers 0 exactly when aa_resample_fwd() will not need one.
-bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
+bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw,
+                               int out_f32 = 0, int out_layout = AA_NCHW);
 bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);

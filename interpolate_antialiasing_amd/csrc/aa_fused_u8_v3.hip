@@ -5,15 +5,19 @@
 
 // Everything the kernel needs that can be known without the pointers (aa_workspace_bytes asks before they exist).
 static bool v3_shape_ok(int dtype, int layout, int64_t N, int64_t Cin, int64_t H, int64_t W, const aa_axis &ah, const aa_axis &aw, bool *flt_out,
-                        bool *planar_out, int *tw_out) {
+                        bool *planar_out, int *tw_out, int out_f32 = 0, int out_layout = AA_NCHW) {
   if (dtype != AA_U8) return false;
+  if (out_f32 && (ah.kind != AA_TABLE_F32 || aw.kind != AA_TABLE_F32)) return false;  // float output = float arithmetic
   const bool flt = ah.kind == AA_TABLE_F32 && aw.kind == AA_TABLE_F32;  // the reference harness's uint8 semantics
   if (!flt && (ah.kind != AA_TABLE_PIL || aw.kind != AA_TABLE_PIL)) return false;
   // channels_last with 3 or 4 interleaved channels, or planar bytes: NCHW is N*C single-channel images
   const bool planar = layout == AA_NCHW || Cin == 1;
   const int C = planar ? 1 : (int)Cin;
   if (C != 1 && C != 3 && C != 4) return false;
+  // a planar wave holds one channel: it can write its own float plane, not an interleaved pixel
+  if (out_f32 && planar && Cin != 1 && out_layout != AA_NCHW) return false;
   const int64_t oH = ah.out_size, oW = aw.out_size;
+  if (out_f32 && (uint64_t)oH * oW * (planar ? 1 : Cin) * 4 > 0xFFFFFFF0ull) return false;
   // the in-register vertical pass needs the H table's scatter section and at most 4 open output rows
   if (ah.scatter_off <= 0 || ah.scatter_max <= 0 || ah.scatter_max > 4) return false;
   if (H < oH) return false;  // down-scaling (or equal) in H: output rows complete one at a time, in order
@@ -33,16 +37,17 @@ static bool v3_shape_ok(int dtype, int layout, int64_t N, int64_t Cin, int64_t H
   return true;
 }
 
-bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw) {
+bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw,
+                               int out_f32, int out_layout) {
   bool flt, planar;
   int tw;
-  return ah && aw && v3_shape_ok(dtype, layout, N, C, H, W, *ah, *aw, &flt, &planar, &tw);
+  return ah && aw && v3_shape_ok(dtype, layout, N, C, H, W, *ah, *aw, &flt, &planar, &tw, out_f32, out_layout);
 }
 
 int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   bool flt, planar;
   int tw;
-  if (!v3_shape_ok(q.dtype, q.layout, q.N, q.C, q.H, q.W, q.ah, q.aw, &flt, &planar, &tw)) return 0;
+  if (!v3_shape_ok(q.dtype, q.layout, q.N, q.C, q.H, q.W, q.ah, q.aw, &flt, &planar, &tw, q.out_f32, q.out_layout)) return 0;
   const int C = planar ? 1 : (int)q.C;
   const int64_t NI = planar ? q.N * q.C : q.N;  // images the kernel sees
   if (((uintptr_t)q.out & 3) != 0) return 0;
@@ -52,7 +57,11 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   p.H = (int)q.H; p.W = (int)q.W; p.oH = (int)q.oH; p.oW = (int)q.oW;
   p.ksize_w = q.aw.ksize; p.ksize_h = q.ah.ksize;
   p.img_in_bytes = (unsigned long long)q.H * q.W * C;
-  p.img_out_bytes = (unsigned long long)q.oH * q.oW * C;
+  p.img_out_bytes = (unsigned long long)q.oH * q.oW * C * (q.out_f32 ? 4 : 1);
+  p.outm = q.out_f32 ? (planar || q.out_layout == AA_NCHW ? 1 : 2) : 0;
+  p.normalize = q.out_f32 ? q.normalize : 0;
+  p.cin = (int)q.C;
+  for (int c = 0; c < 4; c++) { p.mean[c] = q.mean[c]; p.std[c] = q.std[c]; }
   p.in_mis = (int)((uintptr_t)q.in & 15);
   p.total_in_bytes = p.img_in_bytes * (unsigned long long)NI + (unsigned long long)p.in_mis;
   p.total_out_bytes = p.img_out_bytes * (unsigned long long)NI;
@@ -82,7 +91,8 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   const int rc = C == 3   ? aa_v3_launch_c3(tw, q.ah.scatter_max, flt, p, q, lds)
                  : C == 4 ? aa_v3_launch_c4(tw, q.ah.scatter_max, flt, p, q, lds)
                           : aa_v3_launch_c1(tw, q.ah.scatter_max, flt, p, q, lds);
-  if (rc == 1) *variant = flt ? (planar ? "fused_u8_planar_harness_v3" : "fused_u8_nhwc_harness_v3")
+  if (rc == 1 && q.out_f32) *variant = planar ? "fused_u8_planar_to_f32_v3" : (p.outm == 1 ? "fused_u8_nhwc_to_f32_nchw_v3" : "fused_u8_nhwc_to_f32_nhwc_v3");
+  else if (rc == 1) *variant = flt ? (planar ? "fused_u8_planar_harness_v3" : "fused_u8_nhwc_harness_v3")
                         : (planar ? "fused_u8_planar_pil_v3" : "fused_u8_nhwc_pil_v3");
   return rc;
 }

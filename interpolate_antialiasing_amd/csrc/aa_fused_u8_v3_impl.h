@@ -42,6 +42,18 @@
 #define AA_V3_AUX 0  // cache-policy bits of the staging DMA (developer knob)
 #endif
 
+#ifndef AA_V3_PRIO
+#define AA_V3_PRIO 0  // developer knob: 1 = raise the wave's issue priority around its staging DMA
+#endif
+#ifndef AA_V3_DMA_EARLY
+#define AA_V3_DMA_EARLY 0  // developer knob: 1 = refill a slot as soon as its window is in registers (before the row's arithmetic)
+#endif
+
+#ifndef AA_V3_BURST
+#define AA_V3_BURST 1  // staging DMAs are issued in bursts of this many rows (divides G): a wave then meets a vector-memory
+                       // instruction - where it blocks, in order, while the CU's address FIFO is full - every BURST rows
+#endif
+
 #ifndef AA_V3_UNALIGNED
 #define AA_V3_UNALIGNED 0  // 1: window reads straight from the window's BYTE address (gfx950's LDS does serve unaligned
                            // ds_read_b32/b64, and hipcc emits them for align-1 pointers), saving the 5 v_alignbyte per row.
@@ -63,6 +75,11 @@ struct FusedU8V3Params {
   unsigned long long img_in_bytes, img_out_bytes, total_in_bytes, total_out_bytes;
   long long n_images;  // = N for channels_last, N*C for planar input
   int spb_forced;      // strips_per_block comes from the AA_V3_SPB experiment knob: keep it
+  // float-arithmetic kernels only: 0 = uint8 output in the input's layout (the harness's truncating byte()); 1 = float32
+  // output, channel planes (NCHW); 2 = float32 output, interleaved channels (NHWC) — the fp32 result itself, before any
+  // byte(): what np.asarray(pil) -> transpose -> .float() -> op gives (test.py:337-339,55), optionally (v - mean) / std
+  int outm, normalize, cin;
+  float mean[4], std[4];
 };
 
 namespace {
@@ -194,6 +211,13 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   if (out_rem > 0xFFFFFFFFull) out_rem = 0xFFFFFFFFull;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(out + out_off), 0, (unsigned)out_rem, 0x00020000);
   const unsigned out_row_bytes = (unsigned)p.oW * C;
+  float nm_mean[C], nm_std[C];  // (float output with normalisation only)
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    const int ch = C == 1 ? (int)(n % (p.cin > 0 ? p.cin : 1)) : c;  // planar input: this wave's plane is channel n % Cin
+    nm_mean[c] = FLT ? p.mean[ch & 3] : 0.f;
+    nm_std[c] = FLT ? p.std[ch & 3] : 1.f;
+  }
   unsigned store_voff;
   bool store_lane;
   unsigned perm_sel = 0;
@@ -225,6 +249,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 
   auto dma = [&](unsigned a_row, int slot) {
     if (AA_V3_ABL == 4) return;
+    if (AA_V3_PRIO) __builtin_amdgcn_s_setprio(3);
     const unsigned soff = AA_V3_ABL == 7 ? (a_row & 0x3F0u) : (a_row & ~15u);  // 7: every DMA hits the same 1.6 KB
     const int dst = lds_base + slot * p.seg_bytes;
     if (dma_lane0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, soff, 0, AA_V3_AUX);
@@ -232,6 +257,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       if (dma_lane1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst + 1024), 16, voff + 1024, soff, 0, AA_V3_AUX);
     }
+    if (AA_V3_PRIO) __builtin_amdgcn_s_setprio(0);
   };
   // per-slot loop invariants of the window reads (PERIODIC only): dword-aligned LDS address and 16-byte phase
   unsigned slot_ra[G];
@@ -282,7 +308,40 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     return (unsigned)(int)a;
   };
   auto emit = [&](int oy) {  // accumulator set 0 is complete: clip, pack, merge quads, store; then slide the sets down
-    if constexpr (C == 3) {
+    bool stored = false;
+    if constexpr (FLT) {
+      if (p.outm != 0) {  // (wave-uniform) float32 output: the accumulators themselves, one 256-byte row piece per plane
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          v[c] = __int_as_float(A[0][c]);
+          if (p.normalize) v[c] = (v[c] - nm_mean[c]) / nm_std[c];
+        }
+        if (p.outm == 1) {
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (active)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[c]), orsrc, (unsigned)(ox0 + lane) * 4u,
+                                                    ((unsigned)c * (unsigned)p.oH + (unsigned)oy) * (unsigned)p.oW * 4u, 0);
+        } else {
+          const unsigned fv = (unsigned)(ox0 + lane) * (unsigned)(4 * C), fs = (unsigned)oy * (unsigned)p.oW * (unsigned)(4 * C);
+          if constexpr (C == 3) {
+            typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+            const u32x3 t = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
+            if (active) __builtin_amdgcn_raw_buffer_store_b96(t, orsrc, fv, fs, 0);
+          } else if constexpr (C == 4) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 t = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+            if (active) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, fv, fs, 0);
+          } else {
+            if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), orsrc, fv, fs, 0);
+          }
+        }
+        stored = true;
+      }
+    }
+    if (stored) {
+    } else if constexpr (C == 3) {
       const unsigned t = FLT ? (trunc8(A[0][0]) | (trunc8(A[0][1]) << 8) | (trunc8(A[0][2]) << 16))
                              : pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][2]);
       const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xF, 0xF, false);
@@ -406,7 +465,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       if (full_group) __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int i = 0; i < G; i++) {
-        if (AA_V3_ABL != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_row * (G - 2)) : "memory");
+        // (rows up to x - i % BURST - 1 + G have been issued: G - 2 - i % BURST of them are younger than row x+1)
+        if (AA_V3_ABL != 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_row * (G - 2 - (i % AA_V3_BURST))) : "memory");
         // Order matters for the lgkm counter (LDS and scalar loads share it and scalar loads return out of order,
         // so every wait is lgkmcnt(0)): first consume the reads issued a whole row ago (no stall), THEN issue the
         // next row's window reads and scatter record, which land while this row's ~45 VALU instructions run.
@@ -417,6 +477,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           sc1 = load_scatter(r + 1);
           sa1 = fetch(a + row_bytes, (i + 1) % G, d1);
           __builtin_amdgcn_sched_barrier(0);
+          if (AA_V3_DMA_EARLY) { dma(a + (unsigned)G * row_bytes, i); __builtin_amdgcn_sched_barrier(0); }
           row_step(v, sc0);
         } else {
           realign(d1, sa1, v);
@@ -424,9 +485,17 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           sc0 = load_scatter(r + 1);
           sa0 = fetch(a + row_bytes, (i + 1) % G, d0);
           __builtin_amdgcn_sched_barrier(0);
+          if (AA_V3_DMA_EARLY) { dma(a + (unsigned)G * row_bytes, i); __builtin_amdgcn_sched_barrier(0); }
           row_step(v, sc1);
         }
-        dma(a + (unsigned)G * row_bytes, i);  // the slot just consumed gets row x+G
+        if (!AA_V3_DMA_EARLY) {
+          if constexpr (AA_V3_BURST == 1) {
+            dma(a + (unsigned)G * row_bytes, i);  // the slot just consumed gets row x+G
+          } else if ((i % AA_V3_BURST) == AA_V3_BURST - 1) {  // the last BURST slots are free: rows x-BURST+1+G .. x+G
+#pragma unroll
+            for (int b = AA_V3_BURST - 1; b >= 0; b--) dma(a + (unsigned)(G - b) * row_bytes, i - b);
+          }
+        }
         a += row_bytes;
         r++;
         __builtin_amdgcn_sched_barrier(0);  // keep the unrolled rows from interleaving: it only costs registers

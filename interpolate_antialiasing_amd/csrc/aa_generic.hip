@@ -186,6 +186,66 @@ int aa_launch_generic_fwd(const AAProblem &p, const char **variant) {
   return AA_ERR_BAD_DTYPE;
 }
 
+// ---- decode-adjacent conversion, generic form: uint8 in -> fp32 horizontal pass (input layout) -> this vertical pass, which
+// writes float32 in the REQUESTED layout (threads walk the output in its own order: coalesced stores) and applies the optional
+// per-channel (v - mean) / std.  Same arithmetic as the harness path (PipeF32, taps in order).
+namespace {
+struct ConvertArgs { int in_nhwc, out_nhwc, normalize; float mean[4], std[4]; };
+__global__ void __launch_bounds__(256)
+vpass_convert(const float *__restrict__ mid, float *__restrict__ out, const char *__restrict__ table, int64_t total, int C, int H,
+              int oH, int oW, int ksize, const ConvertArgs cv) {
+  const TableView<float> tv = make_table_view<float>(table, oH, ksize);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    int c, ox, oy;
+    int64_t n;
+    if (cv.out_nhwc) {
+      c = (int)(idx % C); int64_t t = idx / C;
+      ox = (int)(t % oW); t /= oW;
+      oy = (int)(t % oH); n = t / oH;
+    } else {
+      ox = (int)(idx % oW); int64_t t = idx / oW;
+      oy = (int)(t % oH); t /= oH;
+      c = (int)(t % C); n = t / C;
+    }
+    const int ymin = tv.xmin[oy];
+    int cnt = tv.xsize[oy];
+    cnt = cnt > 1 ? cnt : 1;
+    const float *w = tv.w + (size_t)oy * ksize;
+    const float *src;
+    int64_t rstride;
+    if (cv.in_nhwc) { src = mid + (((n * H + ymin) * oW + ox) * C + c); rstride = (int64_t)oW * C; }
+    else { src = mid + (((n * C + c) * H + ymin) * oW + ox); rstride = oW; }
+    float acc = src[0] * w[0];
+    for (int j = 1; j < cnt; j++) acc = acc + src[j * rstride] * w[j];
+    if (cv.normalize) acc = (acc - cv.mean[c & 3]) / cv.std[c & 3];
+    out[idx] = acc;
+  }
+}
+}  // namespace
+
+int aa_launch_generic_convert(const AAProblem &p, const char **variant) {
+  if (p.dtype != AA_U8 || p.aw.kind != AA_TABLE_F32 || p.ah.kind != AA_TABLE_F32) return AA_ERR_BAD_DTYPE;
+  const int64_t N = p.N, C = p.C, H = p.H, W = p.W, oH = p.oH, oW = p.oW;
+  if (p.normalize && C > 4) return AA_ERR_BAD_SHAPE;
+  const bool nhwc = p.layout == AA_NHWC;
+  const int inner = nhwc ? (int)C : 1;
+  const int64_t hrows = nhwc ? N * H : N * C * H;
+  const int64_t htotal = hrows * oW * inner;
+  float *mid = (float *)p.ws;
+  hipLaunchKernelGGL((hpass_generic<PipeF32, uint8_t, float>), dim3(grid_for(htotal)), dim3(256), 0, p.stream,
+                     (const uint8_t *)p.in, mid, (const char *)p.aw.table_dev, htotal, (int)W, (int)oW, inner, p.aw.ksize);
+  ConvertArgs cv;
+  cv.in_nhwc = nhwc; cv.out_nhwc = p.out_layout == AA_NHWC; cv.normalize = p.normalize;
+  for (int i = 0; i < 4; i++) { cv.mean[i] = p.mean[i]; cv.std[i] = p.std[i]; }
+  const int64_t vtotal = N * C * oH * oW;
+  hipLaunchKernelGGL(vpass_convert, dim3(grid_for(vtotal)), dim3(256), 0, p.stream, (const float *)mid, (float *)p.out,
+                     (const char *)p.ah.table_dev, vtotal, (int)C, (int)H, (int)oH, (int)oW, p.ah.ksize, cv);
+  AA_HIP_CHECK_LAUNCH();
+  *variant = "generic_2pass_u8_to_f32";
+  return AA_OK;
+}
+
 // one pass along one axis of [outer][in_size][inner]
 template <typename Pipe, typename T>
 static int run_axis(const void *in, void *out, int64_t outer, int64_t in_size, int64_t inner, const aa_axis &ax, hipStream_t stream) {

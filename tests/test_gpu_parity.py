@@ -695,3 +695,54 @@ def test_workspace_answer_matches_dispatch(aa):
         assert torch.equal(y, y0), (shape, size, v)
         exp = oracle.pil_resize_u8("cubic" if fn is aa.cubic_forward else "linear", x[:1].cpu().numpy(), tuple(size))
         assert np.array_equal(y[:1].cpu().numpy(), exp), (shape, size, v)
+
+
+# ------------------------------------------------------------------------------------------------ §8f-3: decode-adjacent fusion
+def test_u8_to_float_conversion_fused(aa, golden_kat):
+    """uint8 HWC / CHW in -> float32 out in ONE launch (test.py:337-339,55: np.asarray(pil) -> transpose -> .float() -> op):
+    bit-identical to the oracle's fp32 forward on the converted image (= the harness arithmetic before its byte()), at the
+    BASELINE config-1 size on the reference's own image, in every layout pair, with and without (v - mean) / std."""
+    from interpolate_antialiasing_amd import _lib
+
+    rgb = golden_kat["rgb"]                                     # [438, 906, 3] uint8, as PIL holds it
+    chw = np.ascontiguousarray(rgb.transpose(2, 0, 1))[None]
+    exp = {f: oracle.forward(f, chw.astype(np.float32), (196, 320)) for f in ("linear", "cubic")}
+    assert np.array_equal(exp["linear"], golden_kat["lin_320x196_f32"])   # = the reference build's own output
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    m32, s32 = np.asarray(mean, np.float32).reshape(1, 3, 1, 1), np.asarray(std, np.float32).reshape(1, 3, 1, 1)
+    hwc = torch.from_numpy(rgb.copy()).cuda()[None].permute(0, 3, 1, 2)  # channels_last view of the HWC bytes
+    planar = torch.from_numpy(chw).cuda()
+    seen = set()
+    for filt in ("linear", "cubic"):
+        fn = _fn(aa, filt)
+        for x, fmts in ((hwc, ("nchw", "nhwc", None)), (planar, ("nchw", None, "nhwc"))):
+            for fmt in fmts:
+                y = fn(x, [196, 320], out_dtype=torch.float32, out_format=fmt)
+                seen.add(_lib.last_variant())
+                assert y.dtype == torch.float32 and tuple(y.shape) == (1, 3, 196, 320)
+                want_cl = (fmt == "nhwc") or (fmt is None and x is hwc)
+                assert y.is_contiguous(memory_format=torch.channels_last if want_cl else torch.contiguous_format)
+                assert np.array_equal(y.cpu().numpy(), exp[filt]), (filt, fmt, _lib.last_variant())
+                yn = fn(x, [196, 320], out_dtype=torch.float32, out_format=fmt, mean=mean, std=std)
+                assert np.array_equal(yn.cpu().numpy(), (exp[filt] - m32) / s32), (filt, fmt, "normalised")
+    assert {"fused_u8_nhwc_to_f32_nchw_v3", "fused_u8_nhwc_to_f32_nhwc_v3", "fused_u8_planar_to_f32_v3",
+            "generic_2pass_u8_to_f32"} <= seen, seen
+    # batched, 4 channels, up-scaling (generic form), fused == generic
+    torch.manual_seed(21)
+    x4 = torch.randint(0, 256, (3, 200, 301, 4), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
+    for size in ([77, 100], [300, 100], [64, 512]):
+        try:
+            _lib.set_fused(1)
+            y1 = aa.linear_forward(x4, size, out_dtype=torch.float32, out_format="nchw", mean=[1, 2, 3, 4], std=[2, 3, 4, 5])
+            _lib.set_fused(0)
+            y0 = aa.linear_forward(x4, size, out_dtype=torch.float32, out_format="nchw", mean=[1, 2, 3, 4], std=[2, 3, 4, 5])
+        finally:
+            _lib.set_fused(1)
+        assert torch.equal(y1, y0), size
+        ref = oracle.forward("linear", x4[:1].cpu().numpy().astype(np.float32), tuple(size))
+        refn = (ref - np.asarray([1, 2, 3, 4], np.float32).reshape(1, 4, 1, 1)) / np.asarray([2, 3, 4, 5], np.float32).reshape(1, 4, 1, 1)
+        assert np.array_equal(y1[:1].cpu().numpy(), refn), size
+    with pytest.raises(NotImplementedError):
+        aa.linear_forward(hwc.float(), [196, 320], out_dtype=torch.float32)
+    with pytest.raises(NotImplementedError):
+        aa.linear_forward(hwc, [196, 320], out_dtype=torch.float32, uint8_mode="pil")
