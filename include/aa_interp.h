@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AA_INTERP_ABI_VERSION 1
+#define AA_INTERP_ABI_VERSION 2
 
 typedef void *aa_stream_t; /* hipStream_t */
 
@@ -82,7 +82,9 @@ typedef struct aa_table_header {
   int32_t span64p1;      /* 1 + max_i (xmin[min(i+63,out-1)] - xmin[i]): how far the window starts of 64 consecutive outputs
                             spread, measured by the device kernel from the table itself (explicit scale factors and
                             align_corners make it differ from 63*in/out); 0 = not measured */
-  int32_t reserved[3];
+  int32_t span4p1;       /* the same over 4 consecutive outputs: 1 + max_i (xmin[min(i+3,out-1)] - xmin[i]) (kernels in which
+                            a lane computes 4 neighbouring outputs from one shared window) */
+  int32_t reserved[2];
 } aa_table_header;
 /* Scatter section (AA_TABLE_PIL and AA_TABLE_F32 tables), used by the fused kernels whose vertical pass runs in registers:
  * one 32-byte record per INPUT index x (in_size + 1 records; the last is an all-zero sentinel a reader may prefetch):
@@ -105,6 +107,8 @@ typedef struct aa_axis {
   int32_t scatter_max;
   int32_t span64p1;      /* from the table header; 0 = unknown: the fused single-launch kernels then decline (they size
                             their staged row segments from it) and the generic two-launch path runs */
+  int32_t span4p1;       /* from the table header; 0 = unknown */
+  int32_t reserved[3];
 } aa_axis;
 
 /* Version / diagnostics. */

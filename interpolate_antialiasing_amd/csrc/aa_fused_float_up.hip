@@ -4,20 +4,27 @@
 //
 // aa_fused_float.hip keeps its vertical pass in registers in scatter form, which needs every output row to complete
 // once and in order — true when the height shrinks.  When it grows, every input row feeds several output rows and an
-// output row needs only the last few input rows, so the vertical pass runs in GATHER form over a small register ring:
-//   * one wave = one strip of <=64 output columns of one band of one (n, c) plane, strips of a band share a workgroup
-//     without barriers (as in aa_fused_float.hip);
-//   * input-row segments are staged into a private G-slot LDS ring by LDS-DMA, G-1 rows ahead;
-//   * horizontal pass of an input row: taps from LDS, accumulated in the reference's order (tap 0 first, product and
-//     sum rounded separately, taps beyond a lane's xsize not added at all); the result is pushed into a ring of the KR
-//     most recent rows, in registers;
-//   * an output row is the weighted sum of the last ysize ring entries with the wave-uniform weights of its table row
-//     (scalar loads, prefetched one output row ahead), again tap 0 first: the same arithmetic, in the same order, as the
-//     generic vertical pass;
-//   * one coalesced 256-byte store per wave per output row.  The path is write-bound: 4.76 MB out per 0.75 MB in for the
-//     backward of config A.
-// Output stores and staging DMAs share the in-order vmcnt counter, and there are ~2 stores per DMA here, so the wave
-// keeps the issue index of every slot's DMA and waits for exactly the operations older than it.
+// output row needs only the last few input rows, so the vertical pass runs in GATHER form over a small register ring.
+// This path is write-bound (4.76 MB out per 0.75 MB in for the backward of config A) and its arithmetic is tiny (2-4 taps
+// each way), so what it costs is per-row overhead: round 1's kernel, one output column per lane, spent 48 scalar and 13
+// vector instructions per 244-byte row piece (profiles/r02_pmc_bwd_before.json: 261 M SALU vs 69 M VALU per launch).
+// Second design (round 2):
+//   * a lane computes CPL = 4 (or 2, or 1) NEIGHBOURING output columns, so a wave covers a strip of 256 columns and a
+//     finished output row leaves as ONE 1-KiB store instruction (16 bytes per lane): 4x fewer wave-rows, 4x less
+//     per-row scalar work per byte;
+//   * the 4 windows of a lane overlap (heights and widths grow here), so the lane reads their UNION once per input row
+//     (U = taps + spread of 4 neighbouring window starts, measured by the table kernel: header.span4p1) and every output
+//     accumulates over the union with its own weights; positions outside an output's own taps are skipped with scalar
+//     lane masks exactly as in aa_fused_float.hip (never added with a zero weight: no non-finite neighbour leaks in, sums
+//     are the reference's bit for bit: tap 0 first, product and sum rounded separately, -ffp-contract=off);
+//   * input-row segments are staged into a private G-slot LDS ring by LDS-DMA, the source rounded down to a multiple of
+//     four floats OF THE ROW (constant phase of the LDS image, see aa_fused_float.hip);
+//   * the horizontal-pass results of the KR most recent input rows live in a register ring; an output row is emitted as
+//     soon as its last input row has been pushed, so its window is always the ring's LAST ysize entries: the gather is
+//     one of KR static unrollings selected by ysize alone; weights come from the table row by scalar loads issued one
+//     output row ahead;
+//   * output stores and staging DMAs share the in-order vmcnt counter and there are ~2 stores per DMA, so the wave keeps
+//     the issue index of every slot's DMA and waits for exactly the operations older than it (a 4-level decision tree).
 
 #include <math.h>
 #include <stdio.h>
@@ -34,27 +41,42 @@ struct FusedF32UpParams {
   int ksize_w, ksize_h;
   int ybands, nstrips, strips_per_block, strip_w;
   int nseg, seg_bytes;
-  int in_mis;
   unsigned long long plane_in_bytes, plane_out_bytes, total_in_bytes, total_out_bytes;
   long long n_groups;  // (plane, band) groups = planes * ybands
 };
 
-__device__ inline void wait_vmcnt_up(int n) {  // rounding n DOWN only waits longer
-  if (n >= 32) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); return; }
-  if (n >= 24) { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); return; }
-  if (n >= 16) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); return; }
-  if (n >= 12) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); return; }
-  if (n >= 8) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); return; }
-  if (n >= 6) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); return; }
-  if (n >= 4) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); return; }
-  if (n >= 3) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); return; }
+__device__ inline void wait_vmcnt_up(int n) {  // rounding n DOWN only waits longer; a decision tree, not a chain
+  if (n >= 6) {
+    if (n >= 16) {
+      if (n >= 32) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); return; }
+      if (n >= 24) { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); return; }
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      return;
+    }
+    if (n >= 12) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); return; }
+    if (n >= 8) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); return; }
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    return;
+  }
+  if (n >= 3) {
+    if (n >= 4) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); return; }
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    return;
+  }
   if (n >= 2) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); return; }
   if (n >= 1) { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); return; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// TW: horizontal taps per lane; G: staged rows; KR: vertical taps kept in registers (>= max ysize of the H table).
-template <int TW, int G, int KR>
+__device__ inline float select_by_mask_up(float a, float b, unsigned long long mask) {  // mask[lane] ? b : a
+  float d;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(mask));
+  return d;
+}
+
+// U: floats a lane reads per input row (the union of its CPL windows); G: staged rows; KR: vertical taps kept in registers
+// (>= max ysize of the H table); CPL: neighbouring output columns per lane (a strip is 64 * CPL columns).
+template <int U, int G, int KR, int CPL>
 __global__ void __launch_bounds__(512)
 fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, const char *__restrict__ tab_w,
                          const char *__restrict__ tab_h, const FusedF32UpParams p) {
@@ -89,36 +111,45 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   const int yls = __builtin_amdgcn_readfirstlane(ysize_h[oy1 - 1]);
   const int r_stop = ylm + (yls > 1 ? yls : 1);  // one past the last input row this band reads
 
-  // ---- per-lane horizontal-pass state (as aa_fused_float.hip) ---------------------------------------------------
-  const bool active = lane < bw;
-  const int ox = ox0 + (active ? lane : 0);
-  const int xm = xmin_w[ox];
-  int xs = xsize_w[ox];
-  xs = xs > 1 ? xs : 1;  // tap 0 is unconditional in the reference (s2.2:68-73)
-  int lead = xm + TW - p.W;  // right-align windows whose unused tail would leave the row
-  lead = lead > 0 ? lead : 0;
-  const int start = xm - lead;
-  float wreg[TW];
-#pragma unroll
-  for (int j = 0; j < TW; j++) {
-    const int src = j - lead;
-    wreg[j] = (src >= 0 && src < xs && src < p.ksize_w) ? kw[(size_t)ox * p.ksize_w + src] : 0.0f;
+  // ---- per-lane horizontal-pass state: CPL outputs sharing one union window of U floats ------------------------------
+  const int col0 = lane * CPL;                 // first column of the lane inside the strip
+  const bool any_active = col0 < bw;
+  const int oxb = ox0 + (any_active ? col0 : 0);  // (lanes beyond the strip duplicate lane 0 and never store)
+  int ustart;  // row position of the union window's first float
+  {
+    const int xm0 = xmin_w[oxb];
+    int hi = p.W - U;  // right-align a union that would leave the row
+    hi = hi > 0 ? hi : 0;
+    ustart = xm0 < hi ? xm0 : hi;
   }
-  const int first_tap = lead;      // register index of the reference's tap 0
-  const int last_tap = lead + xs;  // one past its last tap
+  float wreg[CPL][U];
+  unsigned long long inwin[CPL][U];  // lane masks (scalar registers): union position q is one of output e's own taps
+#pragma unroll
+  for (int e = 0; e < CPL; e++) {
+    const int oxe = (oxb + e < p.oW) ? oxb + e : p.oW - 1;  // (columns beyond the row compute a duplicate, never stored)
+    const int xm = xmin_w[oxe];
+    int xs = xsize_w[oxe];
+    xs = xs > 1 ? xs : 1;  // tap 0 is unconditional in the reference (s2.2:68-73)
+    const int t0 = xm - ustart;  // union position of the reference's tap 0 (>= 0: window starts do not decrease)
+#pragma unroll
+    for (int q = 0; q < U; q++) {
+      const int j = q - t0;
+      const bool mine = j >= 0 && j < xs;
+      wreg[e][q] = (mine && j < p.ksize_w) ? kw[(size_t)oxe * p.ksize_w + j] : 0.0f;
+      inwin[e][q] = __ballot(mine);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on vmcnt counts staging DMAs and output stores only
-  const int seg_first = __builtin_amdgcn_readfirstlane(start * 4);  // lane 0 holds the strip's leftmost window
-  const int c_l = start * 4 - seg_first;
+  const int seg0 = __builtin_amdgcn_readfirstlane(ustart) & ~3;  // lane 0 holds the strip's leftmost window
+  const unsigned lane_lds = (unsigned)(wv * G * p.seg_bytes + (ustart - seg0) * 4);
 
-  const unsigned long long img_off = (unsigned long long)p.in_mis + (unsigned long long)plane * p.plane_in_bytes;
-  const unsigned long long base_off = img_off & ~15ull;
-  unsigned long long remaining = p.total_in_bytes - base_off;
-  if (remaining > 0xFFFFFFFFull) remaining = 0xFFFFFFFFull;
+  const unsigned long long plane_off = (unsigned long long)plane * p.plane_in_bytes;
+  unsigned long long remaining = p.total_in_bytes - plane_off;
+  if (remaining > 0xFFFFFFFCull) remaining = 0xFFFFFFFCull;
   const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)in + base_off), 0, (unsigned)remaining, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)in + plane_off), 0, (unsigned)remaining, 0x00020000);
   const unsigned row_bytes = (unsigned)p.W * 4u;
   const int lds_base = wv * G * p.seg_bytes;
-  const unsigned lane_lds = (unsigned)(lds_base + c_l);
   const bool dma_lane = lane < p.nseg;  // nseg <= 64 (checked on the host)
   const unsigned voff = (unsigned)lane * 16u;
 
@@ -128,18 +159,18 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   const __amdgpu_buffer_rsrc_t orsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)((uint8_t *)out + out_off), 0, (unsigned)out_rem, 0x00020000);
   const unsigned out_row_bytes = (unsigned)p.oW * 4u;
-  const unsigned store_voff = (unsigned)(ox0 + lane) * 4u;
+  const unsigned store_voff = (unsigned)(ox0 + col0) * 4u;
+  const bool full_lane = col0 + CPL <= bw;  // all CPL columns of the lane exist: one wide store
 
-  // byte offset (from the descriptor base) of this strip's segment in input row `row`
-  const unsigned a_base = (unsigned)(img_off - base_off) + (unsigned)seg_first;
+  const unsigned a_base = (unsigned)seg0 * 4u;  // byte offset (from the plane) of the strip's segment in row 0
 
   // ---- staging ring bookkeeping ------------------------------------------------------------------------------------
   int vm_issued = 0;  // VMEM instructions (DMAs + stores) this wave has issued since the wait above
   int idxv = 0;       // lane s: value of vm_issued right after the DMA that filled slot s
   auto dma = [&](int row, int slot) {
-    const unsigned a_row = a_base + (unsigned)row * row_bytes;
     const int dst = lds_base + slot * p.seg_bytes;
-    if (dma_lane) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, a_row & ~15u, 0, 0);
+    if (dma_lane)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, a_base + (unsigned)row * row_bytes, 0, 0);
     vm_issued++;
     idxv = (lane == slot) ? vm_issued : idxv;
   };
@@ -153,37 +184,45 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
     }
   }
 
-  float ring[KR];  // horizontal-pass results of input rows top-KR .. top-1
+  float ring[KR][CPL];  // horizontal-pass results of input rows top-KR .. top-1
 #pragma unroll
-  for (int k = 0; k < KR; k++) ring[k] = 0.0f;
+  for (int k2 = 0; k2 < KR; k2++)
+#pragma unroll
+    for (int e = 0; e < CPL; e++) ring[k2][e] = 0.0f;
   int top = r_begin;  // next input row to run the horizontal pass on
   int slot_top = 0;
 
-  // one input row: wait for its DMA, taps from LDS, reference-order accumulation, refill the slot, push the ring
+  // one input row: wait for its DMA, union window from LDS, reference-order accumulation per output, refill, push
   auto hpass_row = [&]() {
     const int my_idx = __builtin_amdgcn_readlane(idxv, slot_top);
     wait_vmcnt_up(vm_issued - my_idx);  // everything issued up to and including that DMA has completed
-    const unsigned a_row = a_base + (unsigned)top * row_bytes;
-    const unsigned sa = lane_lds + (unsigned)(slot_top * p.seg_bytes) + (a_row & 15u);  // multiple of 4
-    const __attribute__((address_space(3))) float *src = (const __attribute__((address_space(3))) float *)(uintptr_t)sa;
-    float d[TW];
+    const __attribute__((address_space(3))) float *src =
+        (const __attribute__((address_space(3))) float *)(uintptr_t)(lane_lds + (unsigned)(slot_top * p.seg_bytes));
+    float d[U];
 #pragma unroll
-    for (int j = 0; j < TW; j++) d[j] = src[j];
-    float acc = 0.0f;
+    for (int q = 0; q < U; q++) d[q] = src[q];
+    float acc[CPL];
 #pragma unroll
-    for (int j = 0; j < TW; j++) {
-      const float prod = d[j] * wreg[j];
-      const float sum = acc + prod;
-      acc = (j == first_tap) ? prod : ((j > first_tap && j < last_tap) ? sum : acc);
+    for (int e = 0; e < CPL; e++) {
+      acc[e] = -0.0f;  // (-0) + x == x exactly: the first own tap is an assignment
+#pragma unroll
+      for (int q = 0; q < U; q++) {
+        const float prod = d[q] * wreg[e][q];
+        const float sum = acc[e] + prod;
+        acc[e] = select_by_mask_up(acc[e], sum, inwin[e][q]);
+      }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the taps are in registers: the slot may be refilled
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the window is in registers: the slot may be refilled
     if (dma_next < r_stop) {
       dma(dma_next, slot_top);
       dma_next++;
     }
 #pragma unroll
-    for (int k = 0; k + 1 < KR; k++) ring[k] = ring[k + 1];
-    ring[KR - 1] = acc;
+    for (int k2 = 0; k2 + 1 < KR; k2++)
+#pragma unroll
+      for (int e = 0; e < CPL; e++) ring[k2][e] = ring[k2 + 1][e];
+#pragma unroll
+    for (int e = 0; e < CPL; e++) ring[KR - 1][e] = acc[e];
     top++;
     slot_top = slot_top + 1 == G ? 0 : slot_top + 1;
   };
@@ -197,33 +236,66 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
     v.s = __builtin_amdgcn_readfirstlane(ysize_h[o]);
     const float *wr = kh + (size_t)o * p.ksize_h;
 #pragma unroll
-    for (int k = 0; k < KR; k++)  // rows are zero padded to ksize_h; never read past the row
-      v.w[k] = (k < p.ksize_h) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wr[k]))) : 0.0f;
+    for (int k2 = 0; k2 < KR; k2++)  // rows are zero padded to ksize_h; never read past the row
+      v.w[k2] = (k2 < p.ksize_h) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wr[k2]))) : 0.0f;
     return v;
   };
 
   VRow cur = load_vrow(oy0);
   for (int oy = oy0; oy < oy1; oy++) {
     const VRow nxt = load_vrow(oy + 1);
-    const int s = cur.s > 1 ? cur.s : 1;
+    int s = cur.s > 1 ? cur.s : 1;
+    s = s < KR ? s : KR;
     const int need = cur.m + s;
     while (top < need) hpass_row();
-    // the window's rows m .. m+s-1 sit at ring[base .. base+s-1], base = KR - (top - m)
-    const int base = KR - (top - cur.m);
-    float acc = 0.0f;
+    // Windows end at non-decreasing rows and the ring was advanced exactly to this one's end (top == need), so the
+    // window's rows m .. m+s-1 are the ring's LAST s entries: ring[KR-s .. KR-1].
+    float res[CPL];
 #pragma unroll
-    for (int bb = 0; bb < KR; bb++) {
-      if (base == bb) {  // wave-uniform: one of the KR static unrollings runs
+    for (int e = 0; e < CPL; e++) res[e] = 0.0f;
 #pragma unroll
-        for (int k = 0; k + bb < KR; k++) {
-          if (k >= s) break;  // taps beyond the window are not added at all
-          const float prod = ring[bb + k] * cur.w[k];
-          acc = (k == 0) ? prod : acc + prod;
+    for (int ss = 1; ss <= KR; ss++) {
+      if (s == ss) {  // wave-uniform: one of the KR static unrollings runs; taps beyond the window are not added at all
+#pragma unroll
+        for (int e = 0; e < CPL; e++) {
+          float acc = ring[KR - ss][e] * cur.w[0];
+#pragma unroll
+          for (int k2 = 1; k2 < ss; k2++) acc = acc + ring[KR - ss + k2][e] * cur.w[k2];
+          res[e] = acc;
         }
       }
     }
-    if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
-    vm_issued++;
+    const unsigned soff = (unsigned)oy * out_row_bytes;
+    // vm_issued may only count instructions that are certainly issued (an all-lanes-off store is branched around): every
+    // count below is guarded by a wave-uniform condition under which lane 0 or the ragged lane really stores
+    if constexpr (CPL == 4) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 t = {__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
+      if (bw >= CPL) {
+        if (full_lane) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 0);
+        vm_issued++;
+      }
+    } else if constexpr (CPL == 2) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 t = {__float_as_uint(res[0]), __float_as_uint(res[1])};
+      if (bw >= CPL) {
+        if (full_lane) __builtin_amdgcn_raw_buffer_store_b64(t, orsrc, store_voff, soff, 0);
+        vm_issued++;
+      }
+    } else {
+      if (any_active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[0]), orsrc, store_voff, soff, 0);
+      vm_issued++;
+    }
+    if constexpr (CPL > 1) {
+      const int ragged = bw % CPL;  // (wave-uniform) columns of the strip's last, partial lane: stored one by one
+#pragma unroll
+      for (int e = 0; e < CPL - 1; e++) {
+        if (e < ragged) {
+          if (col0 == bw - ragged) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[e]), orsrc, store_voff + 4u * e, soff, 0);
+          vm_issued++;
+        }
+      }
+    }
     cur = nxt;
   }
 }
@@ -250,11 +322,11 @@ int pick_ybands_up(int64_t items_per_band, double slots, int taps_h, int64_t H, 
   return (int)ybands;
 }
 
-template <int TW, int G, int KR>
+template <int U, int G, int KR, int CPL>
 int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
-  auto kern = fused_f32_nchw_up_kernel<TW, G, KR>;
+  auto kern = fused_f32_nchw_up_kernel<U, G, KR, CPL>;
   auto resident = [&](int s) {  // workgroups of s strips a CU holds (-1: their rings do not fit a workgroup's LDS)
-    if (lds * s > 64 * 1024) return -1;  // (never for s == 1: a strip's ring is at most 16 KiB)
+    if (lds * s > 64 * 1024) return -1;  // (never for s == 1: a strip's ring is at most 8 KiB)
     int nb = aa_resident_blocks(kern, 64 * s, lds * s);
     if (nb <= 0) {  // a failed query only costs the heuristic its input: estimate from LDS and wave slots
       nb = (int)((160 * 1024) / (lds * s > 0 ? lds * s : 1));
@@ -265,8 +337,7 @@ int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
   };
   // strips of a band share a workgroup unless single-strip workgroups put more waves on a CU (see aa_fused_u8_v3_impl.h)
   int spb = p.strips_per_block;
-  if (spb > 1 && resident(1) > 0 && (resident(spb) < 0 || resident(1) > resident(spb) * spb)) spb = 1;
-  if (resident(spb) < 0) return 0;
+  if (spb > 1 && (resident(spb) < 0 || resident(1) > resident(spb) * spb)) spb = 1;
   p.strips_per_block = spb;
   const int sgroups = (p.nstrips + spb - 1) / spb;
   const size_t lds_blk = lds * spb;
@@ -276,18 +347,49 @@ int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
   p.n_groups = planes * (int64_t)p.ybands;
   const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream,
-                     (const float *)((const uint8_t *)q.in - p.in_mis), (float *)q.out, (const char *)q.aw.table_dev,
-                     (const char *)q.ah.table_dev, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, (const float *)q.in, (float *)q.out,
+                     (const char *)q.aw.table_dev, (const char *)q.ah.table_dev, p);
   AA_HIP_CHECK_LAUNCH();
   return 1;
 }
 
-template <int TW>
+template <int U, int CPL>
 int launch_kr(int kr, const FusedF32UpParams &p, const AAProblem &q, size_t lds) {
-  if (kr <= 2) return launch_k<TW, 8, 2>(p, q, lds);
-  if (kr <= 4) return launch_k<TW, 8, 4>(p, q, lds);
-  return launch_k<TW, 8, 8>(p, q, lds);
+  if (kr <= 2) return launch_k<U, 8, 2, CPL>(p, q, lds);
+  if (kr <= 4) return launch_k<U, 8, 4, CPL>(p, q, lds);
+  return launch_k<U, 8, 8, CPL>(p, q, lds);
+}
+
+// Columns per lane and union width: the widest CPL whose CPL * U lane masks fit the scalar registers (<= 20) and whose
+// strip segment is one DMA instruction (<= 64 pieces); U = taps + spread of CPL neighbouring window starts.
+struct UpGeometry { int cpl, u, nstrips, strip_w, nseg; };
+
+bool up_geometry(int64_t W, const aa_axis &aw, UpGeometry *g) {
+  const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
+  if (taps_w > 8 || aw.span64p1 <= 0 || aw.span4p1 <= 0) return false;
+  const int64_t oW = aw.out_size;
+  const int cands[3] = {4, 2, 1};
+  for (int ci = 0; ci < 3; ci++) {
+    const int cpl = cands[ci];
+    if (cpl > 1 && oW < 64 * cpl) continue;  // narrow outputs: keep the lanes busy
+    // spread of cpl neighbouring window starts (span4p1 - 1 covers 4; 2 neighbours spread at most as much)
+    const int spread = cpl == 1 ? 0 : aw.span4p1 - 1;
+    int u = taps_w + spread;
+    const int opts[6] = {2, 3, 4, 5, 6, 8};
+    int uu = 0;
+    for (int o : opts)
+      if (u <= o) { uu = o; break; }
+    if (uu == 0 || uu * cpl > 20 || W < uu) continue;
+    // floats a strip of 64 * cpl outputs covers: cpl * spread of 64 starts (+3: rounded down to a multiple of 4) + union
+    const int span = cpl * (aw.span64p1 - 1) + cpl + uu + 3;
+    const int nseg = (span * 4 + 15) / 16 + 1;
+    if (nseg > 64) continue;
+    g->cpl = cpl; g->u = uu; g->nseg = nseg;
+    g->strip_w = 64 * cpl;
+    g->nstrips = (int)((oW + g->strip_w - 1) / g->strip_w);
+    return true;
+  }
+  return false;
 }
 
 }  // namespace
@@ -298,46 +400,43 @@ bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t N, int64_t
   if (!ah || !aw || ah->kind != AA_TABLE_F32 || aw->kind != AA_TABLE_F32) return false;
   if (H > ah->out_size) return false;  // shrinking heights: aa_fused_float.hip
   const int taps_h = ah->max_taps > 0 ? ah->max_taps : ah->ksize;
-  const int taps_w = aw->max_taps > 0 ? aw->max_taps : aw->ksize;
-  if (taps_h > 8 || taps_w > 8) return false;
-  const int tw = taps_w <= 2 ? 2 : (taps_w <= 4 ? 4 : 8);
-  if (W < tw) return false;
+  if (taps_h > 8) return false;
+  UpGeometry g;
+  if (!up_geometry(W, *aw, &g)) return false;
   if ((uint64_t)H * W * 4 > 0xFFFFFFF0ull || (uint64_t)ah->out_size * aw->out_size * 4 > 0xFFFFFFF0ull) return false;
-  const int span_px = aa_strip_span_px(*aw, tw);
-  if (span_px < 0 || (span_px * 4 + 15 + 15) / 16 > 64) return false;  // one DMA instruction per staged row
-  if (!aa_grid_fits(N * C * ((aw->out_size + 63) / 64 + 1))) return false;
+  if (!aa_grid_fits(N * C * g.nstrips)) return false;
   return true;
 }
 
 int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   if (!aa_fused_float_nchw_up_applicable(q.dtype, q.layout, q.N, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
-  const int taps_w = q.aw.max_taps > 0 ? q.aw.max_taps : q.aw.ksize;
-  const int tw = taps_w <= 2 ? 2 : (taps_w <= 4 ? 4 : 8);
   if (((uintptr_t)q.out & 3) != 0 || ((uintptr_t)q.in & 3) != 0) return 0;
+  UpGeometry g;
+  up_geometry(q.W, q.aw, &g);
 
   FusedF32UpParams p;
   p.H = (int)q.H; p.W = (int)q.W; p.oH = (int)q.oH; p.oW = (int)q.oW;
   p.ksize_w = q.aw.ksize; p.ksize_h = q.ah.ksize;
   p.plane_in_bytes = (unsigned long long)q.H * q.W * 4;
   p.plane_out_bytes = (unsigned long long)q.oH * q.oW * 4;
-  p.in_mis = (int)((uintptr_t)q.in & 15);
-  p.total_in_bytes = p.plane_in_bytes * (unsigned long long)(q.N * q.C) + (unsigned long long)p.in_mis;
+  p.total_in_bytes = p.plane_in_bytes * (unsigned long long)(q.N * q.C);
   p.total_out_bytes = p.plane_out_bytes * (unsigned long long)(q.N * q.C);
-  p.nstrips = (int)((q.oW + 63) / 64);
-  p.strip_w = (int)((q.oW + p.nstrips - 1) / p.nstrips);
-  p.nstrips = (int)((q.oW + p.strip_w - 1) / p.strip_w);
+  p.nstrips = g.nstrips;
+  p.strip_w = g.strip_w;
   p.strips_per_block = p.nstrips <= 8 ? p.nstrips : 4;
-  const int span_px = aa_strip_span_px(q.aw, tw);
-  p.nseg = (span_px * 4 + 15 + 15) / 16;
+  p.nseg = g.nseg;
   p.seg_bytes = p.nseg * 16;
   p.ybands = 1;
+  p.n_groups = 0;
   const size_t lds = (size_t)8 * p.seg_bytes;
 
-  int rc;
-  if (tw == 2) rc = launch_kr<2>(taps_h, p, q, lds);
-  else if (tw == 4) rc = launch_kr<4>(taps_h, p, q, lds);
-  else rc = launch_kr<8>(taps_h, p, q, lds);
+  int rc = 0;
+#define AA_UP_CASE(UU, CC) if (g.u == UU && g.cpl == CC) rc = launch_kr<UU, CC>(taps_h, p, q, lds)
+  AA_UP_CASE(2, 4); else AA_UP_CASE(3, 4); else AA_UP_CASE(4, 4); else AA_UP_CASE(5, 4);
+  else AA_UP_CASE(2, 2); else AA_UP_CASE(3, 2); else AA_UP_CASE(4, 2); else AA_UP_CASE(5, 2); else AA_UP_CASE(6, 2); else AA_UP_CASE(8, 2);
+  else AA_UP_CASE(2, 1); else AA_UP_CASE(3, 1); else AA_UP_CASE(4, 1); else AA_UP_CASE(5, 1); else AA_UP_CASE(6, 1); else AA_UP_CASE(8, 1);
+#undef AA_UP_CASE
   if (rc == 1) *variant = "fused_f32_nchw_up";
   return rc;
 }

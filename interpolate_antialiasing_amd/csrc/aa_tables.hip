@@ -163,6 +163,10 @@ __global__ void table_span_kernel(char *table, int out_size) {
   int d = xmin[j] - xmin[i];
   if (d < 0) d = 0;
   atomicMax(&((aa_table_header *)table)->span64p1, d + 1);
+  const int j4 = i + 3 < out_size ? i + 3 : out_size - 1;
+  int d4 = xmin[j4] - xmin[i];
+  if (d4 < 0) d4 = 0;
+  atomicMax(&((aa_table_header *)table)->span4p1, d4 + 1);
 }
 
 __global__ void table_write_header(aa_table_header h, char *table) {
@@ -265,6 +269,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
   h.scatter_ksize = 0;
   h.scatter_max = 0;
   h.span64p1 = 0;
+  h.span4p1 = 0;
   if ((kind == AA_TABLE_PIL || kind == AA_TABLE_F32) && scatter_ksize > 0) {
     h.scatter_off = (int32_t)aa_table_total_bytes(kind, out_size, ksize);
     h.scatter_ksize = scatter_ksize;
@@ -314,6 +319,7 @@ int aa_launch_table_transpose(const aa_table_header &fh, const void *table_dev, 
   h.scatter_ksize = 0;
   h.scatter_max = 0;
   h.span64p1 = 0;
+  h.span4p1 = 0;
   char *t = (char *)tr_dev;
   hipLaunchKernelGGL(table_write_header, dim3(1), dim3(64), 0, stream, h, t);
   const int threads = 128;

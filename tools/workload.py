@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""One named workload, a few launches, for rocprofv3 (kernel-trace / PMC passes): tools/workload.py NAME [launches]."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from interpolate_antialiasing_amd import _lib, extension_interpolate as aa  # noqa: E402
+
+name = sys.argv[1]
+launches = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+torch.manual_seed(0)
+dev = "cuda"
+if name == "headline":
+    x = torch.randint(0, 256, (1024, 438, 906, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+    fn = lambda: aa.linear_forward(x, [196, 320])
+elif name == "c2":
+    x = torch.rand(64, 3, 1024, 1024, device=dev) * 255
+    fn = lambda: aa.cubic_forward(x, [224, 224])
+elif name == "c0f32":
+    x = torch.rand(256, 3, 438, 906, device=dev) * 255
+    fn = lambda: aa.linear_forward(x, [196, 320])
+elif name == "shard3":
+    x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+    fn = lambda: aa.linear_forward(x, [320, 196])
+elif name == "harness":
+    x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+    fn = lambda: aa.linear_forward(x, [320, 196], uint8_mode="harness")
+elif name == "convert":
+    x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+    fn = lambda: aa.linear_forward(x, [320, 196], out_dtype=torch.float32, out_format="nchw")
+elif name == "planar":
+    x = torch.randint(0, 256, (1024, 3, 906, 438), dtype=torch.uint8, device=dev)
+    fn = lambda: aa.linear_forward(x, [320, 196])
+elif name == "bwd":
+    x = torch.randn(256, 3, 196, 320, device=dev)
+    fn = lambda: aa.linear_backward(x, [196, 320], [256, 3, 438, 906])
+elif name == "up":
+    x = torch.rand(64, 3, 438, 906, device=dev) * 255
+    fn = lambda: aa.linear_forward(x, [1200, 1200])
+else:
+    raise SystemExit("unknown workload " + name)
+for _ in range(launches):
+    y = fn()
+torch.cuda.synchronize()
+print(name, _lib.last_variant(), tuple(y.shape))
