@@ -69,7 +69,7 @@ def measure_copy_ceiling(dev, nbytes=2 << 30, reps=10):
     dst = torch.empty_like(src)
     stream = torch.cuda.current_stream(dev).cuda_stream
     forms = {}
-    for form in range(4):
+    for form in range(6):
         for _ in range(3):
             _lib.check(L.aa_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, form, stream), "aa_probe_copy")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -79,13 +79,17 @@ def measure_copy_ceiling(dev, nbytes=2 << 30, reps=10):
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1) / reps
+        if form >= 4:  # one-way streams: bytes written (4) or read (5) per second
+            forms["write_only" if form == 4 else "read_only"] = round(nbytes / (ms * 1e-3) / 1e9, 1)
+            continue
         ok = bool(torch.equal(src[:1 << 20], dst[:1 << 20]) and torch.equal(src[-(1 << 20):], dst[-(1 << 20):]))
         if ok:
             forms[form] = round(2.0 * nbytes / (ms * 1e-3) / 1e9, 1)
         dst.zero_()
     del src, dst
     torch.cuda.empty_cache()
-    return (max(forms.values()) if forms else None), forms
+    copies = [v for k, v in forms.items() if isinstance(k, int)]
+    return (max(copies) if copies else None), forms
 
 
 def cpu_baseline(seconds: float = 12.0):

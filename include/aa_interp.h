@@ -203,7 +203,8 @@ int aa_resample_axis_fwd(const void *in_dev, void *out_dev, int dtype, int64_t o
 
 /* Device-to-device copy of `bytes` bytes with 16-byte vector loads/stores, enqueued on `stream`: the probe bench.py times
  * on the box to report the attainable HBM copy ceiling next to the 8 TB/s spec peak.  form 0: one element per
- * thread; 1: grid-stride; 2: four elements per thread, loads in flight before the stores; 3: form 2, streaming (nt) policy. */
+ * thread; 1: grid-stride; 2: four elements per thread, loads in flight before the stores; 3: form 2, streaming (nt) policy;
+ * 4: write only (fills dst); 5: read only (sums src). */
 int aa_probe_copy(const void *src_dev, void *dst_dev, size_t bytes, int form, aa_stream_t stream);
 
 /* Kernel selection, process-wide; returns the previous setting.  1 (default): fused single-launch kernels, newest

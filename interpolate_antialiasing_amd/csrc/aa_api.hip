@@ -368,7 +368,7 @@ int aa_resample_axis_fwd(const void *in_dev, void *out_dev, int dtype, int64_t o
 
 int aa_probe_copy(const void *src_dev, void *dst_dev, size_t bytes, int form, aa_stream_t stream) {
   if (!src_dev || !dst_dev) return AA_ERR_NULL;
-  if ((((uintptr_t)src_dev | (uintptr_t)dst_dev) & 15) != 0 || form < 0 || form > 3) return AA_ERR_BAD_SHAPE;
+  if ((((uintptr_t)src_dev | (uintptr_t)dst_dev) & 15) != 0 || form < 0 || form > 5) return AA_ERR_BAD_SHAPE;
   return aa_launch_probe_copy(src_dev, dst_dev, bytes, form, (hipStream_t)stream);
 }
 

@@ -32,7 +32,7 @@
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct FusedF32Params {
   int H, W, oH, oW;
@@ -63,14 +63,40 @@ __device__ inline float select_by_mask(float a, float b, unsigned long long mask
   return d;
 }
 
-// NQ: aligned 16-byte LDS reads per window (window positions TWP = 4*NQ >= max taps + 3); G: staged rows per wave;
-// NDMA: LDS-DMA instructions per staged row (segments of up to 64 * NDMA 16-byte pieces); MAXC: outputs one input row can feed.
-template <int NQ, int G, int NDMA, int MAXC>
+// element <-> float: 16-bit floats are storage types only: fp32 arithmetic, fp32 intermediate, ONE rounding to
+// nearest even at the store — exactly half(reference_fp32(float(x))), like the generic path's Store<> (aa_generic.hip)
+template <int DT> __device__ inline float elem_to_f32(unsigned bits);  // bits: the element in the low 16 (or all 32) bits
+template <> __device__ inline float elem_to_f32<AA_F32>(unsigned bits) { return __uint_as_float(bits); }
+template <> __device__ inline float elem_to_f32<AA_F16>(unsigned bits) {
+  union { unsigned short u; _Float16 h; } c;
+  c.u = (unsigned short)bits;
+  return (float)c.h;
+}
+template <> __device__ inline float elem_to_f32<AA_BF16>(unsigned bits) { return __uint_as_float(bits << 16); }
+template <int DT> __device__ inline unsigned f32_to_elem(float a);
+template <> __device__ inline unsigned f32_to_elem<AA_F32>(float a) { return __float_as_uint(a); }
+template <> __device__ inline unsigned f32_to_elem<AA_F16>(float a) {
+  union { unsigned short u; _Float16 h; } c;
+  c.h = (_Float16)a;
+  return c.u;
+}
+template <> __device__ inline unsigned f32_to_elem<AA_BF16>(float a) {  // round to nearest even, NaN stays NaN
+  const unsigned u = __float_as_uint(a);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x0040u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// NQ: aligned 16-byte LDS reads per window (window positions TWP = EPQ*NQ >= max taps + EPQ - 1, EPQ = elements per 16
+// bytes); G: staged rows per wave; NDMA: LDS-DMA instructions per staged row (segments of up to 64 * NDMA 16-byte pieces);
+// MAXC: outputs one input row can feed; DT: element type of the planes (AA_F32, AA_F16, AA_BF16).
+template <int NQ, int G, int NDMA, int MAXC, int DT>
 __global__ void __launch_bounds__(512)
-fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, const char *__restrict__ tab_w,
+fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const char *__restrict__ tab_w,
                       const char *__restrict__ tab_h, const FusedF32Params p) {
-  constexpr int TWP = 4 * NQ;
-  constexpr int TW = TWP - 3;  // taps a lane can hold
+  constexpr int ES = DT == AA_F32 ? 4 : 2;  // element bytes
+  constexpr int EPQ = 16 / ES;              // elements per aligned 16-byte read
+  constexpr int TWP = EPQ * NQ;
+  constexpr int TW = TWP - (EPQ - 1);  // taps a lane can hold
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
   const int lane = threadIdx.x & 63;
@@ -115,8 +141,8 @@ fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, con
   int lead = xm + TW - p.W;  // right-align windows whose unused tail would leave the row
   lead = lead > 0 ? lead : 0;
   const int start = xm - lead;            // row position of the lane's first readable float
-  const int astart = start & ~3;          // ... rounded down to the 16-byte grid of the row image
-  const int tap0 = (start & 3) + lead;    // window position of the reference's tap 0
+  const int astart = start & ~(EPQ - 1);        // ... rounded down to the 16-byte grid of the row image
+  const int tap0 = (start & (EPQ - 1)) + lead;  // window position of the reference's tap 0
   float wreg[TWP];
   unsigned long long inwin[TWP];  // lane masks (scalar registers): position q belongs to the lane's own taps
 #pragma unroll
@@ -128,14 +154,17 @@ fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, con
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table loads done: from here on vmcnt counts DMAs and stores
   const int seg0 = __builtin_amdgcn_readfirstlane(astart);  // lane 0 is always active and has the smallest start
-  const unsigned lane_lds = (unsigned)(wv * G * p.seg_bytes + (astart - seg0) * 4);  // multiple of 16
+  const unsigned lane_lds = (unsigned)(wv * G * p.seg_bytes + (astart - seg0) * ES);  // multiple of 16
 
   const unsigned long long plane_off = (unsigned long long)plane * p.plane_in_bytes;
   unsigned long long remaining = p.total_in_bytes - plane_off;
+  // the range check works per dword and rows of 16-bit elements may start on odd halves: serve the tensor's last element
+  // even when its dword straddles the end (the two bytes beyond are never used: positions outside a lane's taps are skipped)
+  if (ES == 2) remaining += 2;
   if (remaining > 0xFFFFFFFCull) remaining = 0xFFFFFFFCull;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)in + plane_off), 0, (unsigned)remaining, 0x00020000);
-  const unsigned row_bytes = (unsigned)p.W * 4u;
+  const unsigned row_bytes = (unsigned)p.W * (unsigned)ES;
   const int lds_base = wv * G * p.seg_bytes;
   const unsigned voff = (unsigned)lane * 16u;
 
@@ -144,11 +173,11 @@ fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, con
   if (out_rem > 0xFFFFFFFFull) out_rem = 0xFFFFFFFFull;
   const __amdgpu_buffer_rsrc_t orsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)((uint8_t *)out + out_off), 0, (unsigned)out_rem, 0x00020000);
-  const unsigned out_row_bytes = (unsigned)p.oW * 4u;
-  const unsigned store_voff = (unsigned)(ox0 + lane) * 4u;
+  const unsigned out_row_bytes = (unsigned)p.oW * (unsigned)ES;
+  const unsigned store_voff = (unsigned)(ox0 + lane) * (unsigned)ES;
 
   // byte offset (from the plane) of the CURRENT row's segment
-  unsigned a = (unsigned)seg0 * 4u + (unsigned)r_begin * row_bytes;
+  unsigned a = (unsigned)seg0 * (unsigned)ES + (unsigned)r_begin * row_bytes;
 
   // ---- vertical-pass state: MAXC accumulators, A[k] belongs to output row o_base + k -----------------------------
   float A[MAXC];
@@ -175,22 +204,29 @@ fused_f32_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, con
     return s;
   };
   auto emit = [&](int oy) {  // accumulator 0 is complete: store it, slide the others down
-    if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(A[0]), orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+    if constexpr (DT == AA_F32) {
+      if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(A[0]), orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+    } else {
+      if (active) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_elem<DT>(A[0]), orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+    }
 #pragma unroll
     for (int k2 = 0; k2 + 1 < MAXC; k2++) A[k2] = A[k2 + 1];
     A[MAXC - 1] = -0.0f;
   };
   // one input row: window from LDS, reference-order accumulation over the lane's own taps, scatter into the open outputs
   auto row_step = [&](int slot, const Scatter &sc) {
-    const __attribute__((address_space(3))) f32x4 *src =
-        (const __attribute__((address_space(3))) f32x4 *)(uintptr_t)(lane_lds + (unsigned)(slot * p.seg_bytes));
-    f32x4 d[NQ];
+    const __attribute__((address_space(3))) u32x4 *src =
+        (const __attribute__((address_space(3))) u32x4 *)(uintptr_t)(lane_lds + (unsigned)(slot * p.seg_bytes));
+    u32x4 d[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) d[q] = src[q];
     float acc = -0.0f;
 #pragma unroll
     for (int q = 0; q < TWP; q++) {
-      const float prod = d[q >> 2][q & 3] * wreg[q];
+      float dq;  // window position q as a float
+      if constexpr (DT == AA_F32) dq = __uint_as_float(d[q >> 2][q & 3]);
+      else dq = elem_to_f32<DT>(d[q >> 3][(q >> 1) & 3] >> (16 * (q & 1)));
+      const float prod = dq * wreg[q];
       const float sum = acc + prod;
       acc = select_by_mask(acc, sum, inwin[q]);
     }
@@ -274,9 +310,9 @@ int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int64_t H, i
   return (int)ybands;
 }
 
-template <int NQ, int G, int NDMA, int MAXC>
+template <int NQ, int G, int NDMA, int MAXC, int DT>
 int launch_k(FusedF32Params p, const AAProblem &q) {
-  auto kern = fused_f32_nchw_kernel<NQ, G, NDMA, MAXC>;
+  auto kern = fused_f32_nchw_kernel<NQ, G, NDMA, MAXC, DT>;
   const size_t lds = (size_t)G * p.seg_bytes;  // per strip (wave)
   auto resident = [&](int s) {  // workgroups of s strips a CU holds (-1: their rings do not fit a workgroup's LDS)
     if (lds * s > 64 * 1024) return -1;  // (never for s == 1: a strip's ring is at most 16 KiB)
@@ -304,47 +340,55 @@ int launch_k(FusedF32Params p, const AAProblem &q) {
   p.n_groups = planes * (int64_t)p.ybands;
   const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, (const float *)q.in, (float *)q.out,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, q.in, q.out,
                      (const char *)q.aw.table_dev, (const char *)q.ah.table_dev, p);
   AA_HIP_CHECK_LAUNCH();
   return 1;
 }
 
-template <int NQ, int G, int NDMA>
+template <int NQ, int G, int NDMA, int DT>
 int launch_m(int maxc, const FusedF32Params &p, const AAProblem &q) {
-  if (maxc <= 2) return launch_k<NQ, G, NDMA, 2>(p, q);
-  if (maxc <= 3) return launch_k<NQ, G, NDMA, 3>(p, q);
-  if (maxc <= 4) return launch_k<NQ, G, NDMA, 4>(p, q);
-  return launch_k<NQ, G, NDMA, 6>(p, q);
+  if (maxc <= 2) return launch_k<NQ, G, NDMA, 2, DT>(p, q);
+  if (maxc <= 3) return launch_k<NQ, G, NDMA, 3, DT>(p, q);
+  if (maxc <= 4) return launch_k<NQ, G, NDMA, 4, DT>(p, q);
+  return launch_k<NQ, G, NDMA, 6, DT>(p, q);
 }
 
 // staged rows per wave: 8 while a row segment is one DMA instruction (<= 1 KiB), 4 beyond (rings stay <= 8 KiB per wave)
-template <int NQ>
+template <int NQ, int DT>
 int launch_q(int maxc, const FusedF32Params &p, const AAProblem &q) {
-  return p.nseg <= 64 ? launch_m<NQ, 8, 1>(maxc, p, q) : launch_m<NQ, 4, 2>(maxc, p, q);
+  return p.nseg <= 64 ? launch_m<NQ, 8, 1, DT>(maxc, p, q) : launch_m<NQ, 4, 2, DT>(maxc, p, q);
 }
 
-// window quads for a table whose widest window has `taps` taps: 4 * NQ - 3 >= taps
-int quads_for(int taps) {
-  const int opts[] = {2, 3, 4, 5, 7};
-  for (int o : opts)
-    if (taps <= 4 * o - 3) return o;
+// window quads for a table whose widest window has `taps` taps: EPQ * NQ - (EPQ - 1) >= taps.  fp32: 2,3,4,5,7 quads of 4
+// floats (5 .. 25 taps); 16-bit floats: 2 or 3 quads of 8 (9 / 17 taps: more positions would not leave scalar registers
+// for their lane masks)
+int quads_for(int taps, int epq) {
+  if (epq == 4) {
+    const int opts[] = {2, 3, 4, 5, 7};
+    for (int o : opts)
+      if (taps <= 4 * o - 3) return o;
+    return 0;
+  }
+  if (taps <= 9) return 2;
+  if (taps <= 17) return 3;
   return 0;
 }
 
 struct F32Geometry { int nq, nstrips, strip_w, nseg; };
 
-bool f32_geometry(int64_t W, const aa_axis &aw, F32Geometry *g) {
+bool f32_geometry(int dtype, int64_t W, const aa_axis &aw, F32Geometry *g) {
+  const int es = dtype == AA_F32 ? 4 : 2, epq = 16 / es;
   const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
-  g->nq = quads_for(taps_w);
-  if (g->nq == 0 || W < 4 * g->nq - 3) return false;
+  g->nq = quads_for(taps_w, epq);
+  if (g->nq == 0 || W < epq * g->nq - (epq - 1)) return false;
   if (aw.span64p1 <= 0) return false;
   const int64_t oW = aw.out_size;
-  g->strip_w = 64;  // whole 128-byte lines per stored row piece (the last strip may be shorter)
+  g->strip_w = 64;  // whole 128-byte lines per stored fp32 row piece (the last strip may be shorter)
   g->nstrips = (int)((oW + 63) / 64);
-  // floats a strip's windows cover: the spread of 64 window starts (+3: the first one rounded down to a multiple of 4)
-  // + one window
-  g->nseg = (aw.span64p1 + 3 + 4 * g->nq + 3) / 4;
+  // elements a strip's windows cover: the spread of 64 window starts (+EPQ-1: the first one rounded down to the 16-byte
+  // grid) + one window; in 16-byte pieces
+  g->nseg = (aw.span64p1 + (epq - 1) + epq * g->nq + (epq - 1)) / epq;
   return g->nseg <= 128;
 }
 
@@ -352,12 +396,12 @@ bool f32_geometry(int64_t W, const aa_axis &aw, F32Geometry *g) {
 
 bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah,
                                     const aa_axis *aw) {
-  if (dtype != AA_F32 || layout != AA_NCHW) return false;
+  if ((dtype != AA_F32 && dtype != AA_F16 && dtype != AA_BF16) || layout != AA_NCHW) return false;
   if (!ah || !aw || ah->kind != AA_TABLE_F32 || aw->kind != AA_TABLE_F32) return false;
   if (ah->scatter_off <= 0 || ah->scatter_max <= 0 || ah->scatter_max > 6) return false;
   if (H < ah->out_size) return false;
   F32Geometry g;
-  if (!f32_geometry(W, *aw, &g)) return false;
+  if (!f32_geometry(dtype, W, *aw, &g)) return false;
   if ((uint64_t)H * W * 4 > 0xFFFFFFF0ull) return false;
   if ((uint64_t)ah->out_size * aw->out_size * 4 > 0xFFFFFFF0ull) return false;
   if (!aa_grid_fits(N * C * g.nstrips)) return false;
@@ -366,15 +410,16 @@ bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t N, int64_t C,
 
 int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
   if (!aa_fused_float_nchw_applicable(q.dtype, q.layout, q.N, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
-  if (((uintptr_t)q.out & 3) != 0 || ((uintptr_t)q.in & 3) != 0) return 0;
+  const int es = q.dtype == AA_F32 ? 4 : 2;
+  if (((uintptr_t)q.out & (es - 1)) != 0 || ((uintptr_t)q.in & (es - 1)) != 0) return 0;
   F32Geometry g;
-  f32_geometry(q.W, q.aw, &g);
+  f32_geometry(q.dtype, q.W, q.aw, &g);
 
   FusedF32Params p;
   p.H = (int)q.H; p.W = (int)q.W; p.oH = (int)q.oH; p.oW = (int)q.oW;
   p.ksize_w = q.aw.ksize; p.ksize_h = q.ah.ksize;
-  p.plane_in_bytes = (unsigned long long)q.H * q.W * 4;
-  p.plane_out_bytes = (unsigned long long)q.oH * q.oW * 4;
+  p.plane_in_bytes = (unsigned long long)q.H * q.W * es;
+  p.plane_out_bytes = (unsigned long long)q.oH * q.oW * es;
   p.total_in_bytes = p.plane_in_bytes * (unsigned long long)(q.N * q.C);
   p.total_out_bytes = p.plane_out_bytes * (unsigned long long)(q.N * q.C);
   p.sc_off = q.ah.scatter_off;
@@ -388,13 +433,19 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
 
   int rc = 0;
   const int mc = q.ah.scatter_max;
-  switch (g.nq) {
-    case 2: rc = launch_q<2>(mc, p, q); break;
-    case 3: rc = launch_q<3>(mc, p, q); break;
-    case 4: rc = launch_q<4>(mc, p, q); break;
-    case 5: rc = launch_q<5>(mc, p, q); break;
-    default: rc = launch_q<7>(mc, p, q); break;
+  if (q.dtype == AA_F32) {
+    switch (g.nq) {
+      case 2: rc = launch_q<2, AA_F32>(mc, p, q); break;
+      case 3: rc = launch_q<3, AA_F32>(mc, p, q); break;
+      case 4: rc = launch_q<4, AA_F32>(mc, p, q); break;
+      case 5: rc = launch_q<5, AA_F32>(mc, p, q); break;
+      default: rc = launch_q<7, AA_F32>(mc, p, q); break;
+    }
+  } else if (q.dtype == AA_F16) {
+    rc = g.nq == 2 ? launch_q<2, AA_F16>(mc, p, q) : launch_q<3, AA_F16>(mc, p, q);
+  } else {
+    rc = g.nq == 2 ? launch_q<2, AA_BF16>(mc, p, q) : launch_q<3, AA_BF16>(mc, p, q);
   }
-  if (rc == 1) *variant = "fused_f32_nchw";
+  if (rc == 1) *variant = q.dtype == AA_F32 ? "fused_f32_nchw" : (q.dtype == AA_F16 ? "fused_f16_nchw" : "fused_bf16_nchw");
   return rc;
 }

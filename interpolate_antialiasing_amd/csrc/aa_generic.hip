@@ -273,7 +273,8 @@ namespace {
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // form 0: one 16-byte element per thread; form 1: grid-stride over a grid of 32 workgroups per CU; form 2: four elements per
 // thread, each wave-instruction a contiguous 1 KiB, all four loads in flight before the first store; form 3: form 2 with
-// the streaming (nt) policy on loads and stores.  bench.py reports the best of them.
+// the streaming (nt) policy on loads and stores; form 4: WRITE ONLY (a fill of dst, nothing read); form 5: READ ONLY (src is
+// summed, one dword per workgroup lands in dst).  bench.py reports the best copy form and the write-only / read-only rates.
 template <int FORM>
 __global__ void __launch_bounds__(256) probe_copy_kernel(const u32x4_t *__restrict__ src, u32x4_t *__restrict__ dst, size_t n16) {
   if constexpr (FORM == 0) {
@@ -282,6 +283,19 @@ __global__ void __launch_bounds__(256) probe_copy_kernel(const u32x4_t *__restri
   } else if constexpr (FORM == 1) {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+  } else if constexpr (FORM == 4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32x4_t v = {(unsigned)i, 1u, 2u, 3u};
+    if (i < n16) dst[i] = v;
+  } else if constexpr (FORM == 5) {
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    unsigned acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const size_t i = base + 256 * k;
+      if (i < n16) { const u32x4_t v = src[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    }
+    if (acc == 0x9e3779b9u) ((unsigned *)dst)[blockIdx.x] = acc;  // (practically never: keeps the loads alive)
   } else {
     const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
     u32x4_t v[4];
@@ -312,14 +326,16 @@ int aa_launch_probe_copy(const void *src, void *dst, size_t bytes, int form, hip
     const size_t cap = (size_t)aa_device_cu_count() * 32;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(probe_copy_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
-  } else if (form == 0) {
+  } else if (form == 0 || form == 4) {
     const size_t blocks = (n16 + 255) / 256;
     if (blocks > 0x7FFFFFFF) return AA_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(probe_copy_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
+    if (form == 0) hipLaunchKernelGGL(probe_copy_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
+    else hipLaunchKernelGGL(probe_copy_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
   } else {
     const size_t blocks = (n16 + 1023) / 1024;
     if (blocks > 0x7FFFFFFF) return AA_ERR_BAD_SHAPE;
     if (form == 2) hipLaunchKernelGGL(probe_copy_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
+    else if (form == 5) hipLaunchKernelGGL(probe_copy_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
     else hipLaunchKernelGGL(probe_copy_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, s, d, n16);
   }
   AA_HIP_CHECK_LAUNCH();

@@ -431,6 +431,28 @@ def test_half_precision_is_rounded_fp32(aa, dtype, channels_last):
         got = _fn(aa, filt)(xg, list(size))
         assert got.dtype == dtype and got.is_contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
         assert torch.equal(got.cpu().view(torch.int16), exp.view(torch.int16)), (filt, shape, size)
+    if not channels_last:
+        # the fused single-launch kernel (16-bit elements staged and read as halves, fp32 arithmetic, one rounding at the store)
+        # at BASELINE sizes, odd widths included (rows that are only 2-byte aligned): bit-identical to the generic path, and to
+        # the oracle on the up-cast input for one image
+        from interpolate_antialiasing_amd import _lib
+
+        want = "fused_f16_nchw" if dtype == torch.float16 else "fused_bf16_nchw"
+        for fn, filt, shape, size in ((aa.linear_forward, "linear", (6, 3, 438, 906), [196, 320]), (aa.cubic_forward, "cubic", (2, 3, 438, 907), [196, 320]),
+                                      (aa.cubic_forward, "cubic", (2, 2, 512, 512), [100, 160]), (aa.nearest_forward, "box", (1, 3, 333, 517), [100, 129])):
+            x = ((torch.rand(shape, device="cuda") * 300) - 40).to(dtype)
+            try:
+                _lib.set_fused(1)
+                y1 = fn(x, size)
+                v = _lib.last_variant()
+                _lib.set_fused(0)
+                y0 = fn(x, size)
+            finally:
+                _lib.set_fused(1)
+            assert v == want, (v, shape, size)
+            assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)), (filt, shape, size)
+            exp1 = torch.from_numpy(oracle.forward(filt, x[:1].float().cpu().numpy(), tuple(size))).to(dtype)
+            assert torch.equal(y1[:1].cpu().view(torch.int16), exp1.view(torch.int16)), (filt, shape, size)
 
 
 def _oracle_axis(filt, a, axis, n_out, align_corners=False):
