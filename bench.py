@@ -184,6 +184,9 @@ def secondary_configs(dev):
     x = torch.rand(256, 3, 438, 906, device=dev) * 255
     add("configs[0] on GPU: fp32 NCHW [256,3,438,906]->[196,320] bilinear", lambda: aa.linear_forward(x, [196, 320]),
         256 * 3 * 4 * (438 * 906 + 196 * 320))
+    x = x.contiguous(memory_format=torch.channels_last)
+    add("fp32 channels_last [256,3,438,906]->[196,320] bilinear", lambda: aa.linear_forward(x, [196, 320]),
+        256 * 3 * 4 * (438 * 906 + 196 * 320))
     del x
     x = torch.rand(64, 3, 1024, 1024, device=dev) * 255
     add("configs[2]: fp32 NCHW [64,3,1024,1024]->[224,224] bicubic", lambda: aa.cubic_forward(x, [224, 224]),

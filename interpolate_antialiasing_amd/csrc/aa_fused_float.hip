@@ -35,7 +35,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct FusedF32Params {
-  int H, W, oH, oW;
+  int H, W, oH, oW;  // W, oW: ELEMENTS per row (pixels * channel stride for interleaved channels)
+  int Wp, oWp;       // pixels per row
   int ksize_w, ksize_h;
   int ybands, nstrips, strips_per_block, strip_w;
   int nseg, seg_bytes;
@@ -89,14 +90,19 @@ template <> __device__ inline unsigned f32_to_elem<AA_BF16>(float a) {  // round
 // NQ: aligned 16-byte LDS reads per window (window positions TWP = EPQ*NQ >= max taps + EPQ - 1, EPQ = elements per 16
 // bytes); G: staged rows per wave; NDMA: LDS-DMA instructions per staged row (segments of up to 64 * NDMA 16-byte pieces);
 // MAXC: outputs one input row can feed; DT: element type of the planes (AA_F32, AA_F16, AA_BF16).
-template <int NQ, int G, int NDMA, int MAXC, int DT>
+// CS: channel stride.  1: planes (NCHW), the aligned-window form described above.  3 / 4: interleaved channels (fp32
+// channels_last, s2.2:752): a "plane" is an image, a row holds W*CS floats, a lane owns one output ELEMENT (pixel ox = e / CS,
+// channel e % CS) so that a wave's row piece is still 256 contiguous bytes; its taps sit CS floats apart, so the window is
+// read tap by tap (ds_read_b32 at the exact tap address: no shift, TWP = 4*NQ taps) — same arithmetic, same order.
+template <int NQ, int G, int NDMA, int MAXC, int DT, int CS = 1>
 __global__ void __launch_bounds__(512)
 fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const char *__restrict__ tab_w,
                       const char *__restrict__ tab_h, const FusedF32Params p) {
   constexpr int ES = DT == AA_F32 ? 4 : 2;  // element bytes
   constexpr int EPQ = 16 / ES;              // elements per aligned 16-byte read
   constexpr int TWP = EPQ * NQ;
-  constexpr int TW = TWP - (EPQ - 1);  // taps a lane can hold
+  constexpr int TW = CS == 1 ? TWP - (EPQ - 1) : TWP;  // taps a lane can hold
+  static_assert(CS == 1 || DT == AA_F32, "interleaved channels: fp32 only");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
   const int lane = threadIdx.x & 63;
@@ -117,8 +123,8 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   const int oy1 = (int)((long long)(yb + 1) * p.oH / p.ybands);
 
   const int32_t *__restrict__ xmin_w = (const int32_t *)(tab_w + aa_table_xmin_off());
-  const int32_t *__restrict__ xsize_w = (const int32_t *)(tab_w + aa_table_xsize_off(p.oW));
-  const float *__restrict__ kw = (const float *)(tab_w + aa_table_w_off(p.oW));
+  const int32_t *__restrict__ xsize_w = (const int32_t *)(tab_w + aa_table_xsize_off(p.oWp));
+  const float *__restrict__ kw = (const float *)(tab_w + aa_table_w_off(p.oWp));
   const int32_t *__restrict__ ymin_h = (const int32_t *)(tab_h + aa_table_xmin_off());
   const int32_t *__restrict__ ysize_h = (const int32_t *)(tab_h + aa_table_xsize_off(p.oH));
   const int32_t *__restrict__ sc_rec = (const int32_t *)(tab_h + p.sc_off);
@@ -133,16 +139,17 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
 
   // ---- per-lane horizontal-pass state ------------------------------------------------------------------------
   const bool active = lane < bw;
-  const int ox = ox0 + (active ? lane : 0);  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
+  const int oe = ox0 + (active ? lane : 0);  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
+  const int ox = CS == 1 ? oe : oe / CS;     // output pixel; channel oe % CS
   const int xm = xmin_w[ox];
   int xs = xsize_w[ox];
   xs = xs > 1 ? xs : 1;  // tap 0 is unconditional in the reference (s2.2:68-73)
   xs = xs < TW ? xs : TW;
-  int lead = xm + TW - p.W;  // right-align windows whose unused tail would leave the row
+  int lead = xm + TW - p.Wp;  // right-align windows whose unused tail would leave the row
   lead = lead > 0 ? lead : 0;
-  const int start = xm - lead;            // row position of the lane's first readable float
-  const int astart = start & ~(EPQ - 1);        // ... rounded down to the 16-byte grid of the row image
-  const int tap0 = (start & (EPQ - 1)) + lead;  // window position of the reference's tap 0
+  const int start = CS == 1 ? xm - lead : (xm - lead) * CS + (oe - ox * CS);  // row position (elements) of the first readable one
+  const int astart = CS == 1 ? (start & ~(EPQ - 1)) : start;  // planes: rounded down to the 16-byte grid of the row image
+  const int tap0 = CS == 1 ? (start & (EPQ - 1)) + lead : lead;  // window position of the reference's tap 0
   float wreg[TWP];
   unsigned long long inwin[TWP];  // lane masks (scalar registers): position q belongs to the lane's own taps
 #pragma unroll
@@ -153,7 +160,9 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
     inwin[q] = __ballot(mine);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table loads done: from here on vmcnt counts DMAs and stores
-  const int seg0 = __builtin_amdgcn_readfirstlane(astart);  // lane 0 is always active and has the smallest start
+  // lane 0 is always active and its PIXEL has the smallest window start (interleaved channels: take its channel 0, a
+  // neighbouring pixel with the same start and a lower channel sits before lane 0's own element)
+  const int seg0 = __builtin_amdgcn_readfirstlane(CS == 1 ? astart : astart - (oe - ox * CS)) & ~(EPQ - 1);
   const unsigned lane_lds = (unsigned)(wv * G * p.seg_bytes + (astart - seg0) * ES);  // multiple of 16
 
   const unsigned long long plane_off = (unsigned long long)plane * p.plane_in_bytes;
@@ -218,13 +227,21 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
     const __attribute__((address_space(3))) u32x4 *src =
         (const __attribute__((address_space(3))) u32x4 *)(uintptr_t)(lane_lds + (unsigned)(slot * p.seg_bytes));
     u32x4 d[NQ];
+    float dt[CS == 1 ? 1 : TWP];  // (interleaved channels: the taps, CS floats apart)
+    if constexpr (CS == 1) {
 #pragma unroll
-    for (int q = 0; q < NQ; q++) d[q] = src[q];
+      for (int q = 0; q < NQ; q++) d[q] = src[q];
+    } else {
+      const __attribute__((address_space(3))) float *st = (const __attribute__((address_space(3))) float *)src;
+#pragma unroll
+      for (int q = 0; q < TWP; q++) dt[q] = st[q * CS];
+    }
     float acc = -0.0f;
 #pragma unroll
     for (int q = 0; q < TWP; q++) {
       float dq;  // window position q as a float
-      if constexpr (DT == AA_F32) dq = __uint_as_float(d[q >> 2][q & 3]);
+      if constexpr (CS != 1) dq = dt[q];
+      else if constexpr (DT == AA_F32) dq = __uint_as_float(d[q >> 2][q & 3]);
       else dq = elem_to_f32<DT>(d[q >> 3][(q >> 1) & 3] >> (16 * (q & 1)));
       const float prod = dq * wreg[q];
       const float sum = acc + prod;
@@ -310,9 +327,9 @@ int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int64_t H, i
   return (int)ybands;
 }
 
-template <int NQ, int G, int NDMA, int MAXC, int DT>
+template <int NQ, int G, int NDMA, int MAXC, int DT, int CS = 1>
 int launch_k(FusedF32Params p, const AAProblem &q) {
-  auto kern = fused_f32_nchw_kernel<NQ, G, NDMA, MAXC, DT>;
+  auto kern = fused_f32_nchw_kernel<NQ, G, NDMA, MAXC, DT, CS>;
   const size_t lds = (size_t)G * p.seg_bytes;  // per strip (wave)
   auto resident = [&](int s) {  // workgroups of s strips a CU holds (-1: their rings do not fit a workgroup's LDS)
     if (lds * s > 64 * 1024) return -1;  // (never for s == 1: a strip's ring is at most 16 KiB)
@@ -335,7 +352,7 @@ int launch_k(FusedF32Params p, const AAProblem &q) {
   const int sgroups = (p.nstrips + spb - 1) / spb;
   const size_t lds_blk = lds * spb;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
-  const int64_t planes = q.N * q.C;
+  const int64_t planes = CS == 1 ? q.N * q.C : q.N;
   p.ybands = pick_ybands_f(planes * sgroups, (double)aa_device_cu_count() * resident(spb), taps_h, q.H, q.oH);
   p.n_groups = planes * (int64_t)p.ybands;
   const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
@@ -346,18 +363,28 @@ int launch_k(FusedF32Params p, const AAProblem &q) {
   return 1;
 }
 
-template <int NQ, int G, int NDMA, int DT>
+template <int NQ, int G, int NDMA, int DT, int CS = 1>
 int launch_m(int maxc, const FusedF32Params &p, const AAProblem &q) {
-  if (maxc <= 2) return launch_k<NQ, G, NDMA, 2, DT>(p, q);
-  if (maxc <= 3) return launch_k<NQ, G, NDMA, 3, DT>(p, q);
-  if (maxc <= 4) return launch_k<NQ, G, NDMA, 4, DT>(p, q);
-  return launch_k<NQ, G, NDMA, 6, DT>(p, q);
+  if (maxc <= 2) return launch_k<NQ, G, NDMA, 2, DT, CS>(p, q);
+  if (maxc <= 3) return launch_k<NQ, G, NDMA, 3, DT, CS>(p, q);
+  if (maxc <= 4) return launch_k<NQ, G, NDMA, 4, DT, CS>(p, q);
+  return launch_k<NQ, G, NDMA, 6, DT, CS>(p, q);
 }
 
 // staged rows per wave: 8 while a row segment is one DMA instruction (<= 1 KiB), 4 beyond (rings stay <= 8 KiB per wave)
-template <int NQ, int DT>
+template <int NQ, int DT, int CS = 1>
 int launch_q(int maxc, const FusedF32Params &p, const AAProblem &q) {
-  return p.nseg <= 64 ? launch_m<NQ, 8, 1, DT>(maxc, p, q) : launch_m<NQ, 4, 2, DT>(maxc, p, q);
+  return p.nseg <= 64 ? launch_m<NQ, 8, 1, DT, CS>(maxc, p, q) : launch_m<NQ, 4, 2, DT, CS>(maxc, p, q);
+}
+
+template <int CS>
+int launch_interleaved(int nq, int maxc, const FusedF32Params &p, const AAProblem &q) {
+  switch (nq) {
+    case 2: return launch_q<2, AA_F32, CS>(maxc, p, q);
+    case 3: return launch_q<3, AA_F32, CS>(maxc, p, q);
+    case 4: return launch_q<4, AA_F32, CS>(maxc, p, q);
+    default: return launch_q<5, AA_F32, CS>(maxc, p, q);
+  }
 }
 
 // window quads for a table whose widest window has `taps` taps: EPQ * NQ - (EPQ - 1) >= taps.  fp32: 2,3,4,5,7 quads of 4
@@ -375,14 +402,31 @@ int quads_for(int taps, int epq) {
   return 0;
 }
 
-struct F32Geometry { int nq, nstrips, strip_w, nseg; };
+struct F32Geometry { int nq, nstrips, strip_w, nseg, cs; };
 
-bool f32_geometry(int dtype, int64_t W, const aa_axis &aw, F32Geometry *g) {
+bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw, F32Geometry *g) {
   const int es = dtype == AA_F32 ? 4 : 2, epq = 16 / es;
   const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
+  g->cs = (layout == AA_NHWC && C > 1) ? (int)C : 1;
+  if (aw.span64p1 <= 0) return false;
+  if (g->cs != 1) {  // interleaved channels (fp32, 3 or 4 of them): a lane per output element, taps read one by one
+    if (dtype != AA_F32 || (C != 3 && C != 4) || aw.span4p1 <= 0) return false;
+    g->nq = taps_w <= 8 ? 2 : (taps_w <= 12 ? 3 : (taps_w <= 16 ? 4 : (taps_w <= 20 ? 5 : 0)));
+    if (g->nq == 0 || W < 4 * g->nq) return false;
+    const int64_t oWe = aw.out_size * C;
+    g->strip_w = 64;
+    g->nstrips = (int)((oWe + 63) / 64);
+    // pixels the strip's 64 elements span: ceil(63 / C) + 1; the spread of their window starts, bounded through the measured
+    // spread of 4 neighbours (3 steps) and of 64
+    const int steps = (63 / (int)C + 1 + 2) / 3;
+    int spread = steps * (aw.span4p1 - 1);
+    if (spread > aw.span64p1 - 1) spread = aw.span64p1 - 1;
+    const int span = (spread + 4 * g->nq) * (int)C + 3 + (int)C;  // elements (+3: segment start rounded down to 4)
+    g->nseg = (span + 3) / 4 + 1;
+    return g->nseg <= 128;
+  }
   g->nq = quads_for(taps_w, epq);
   if (g->nq == 0 || W < epq * g->nq - (epq - 1)) return false;
-  if (aw.span64p1 <= 0) return false;
   const int64_t oW = aw.out_size;
   g->strip_w = 64;  // whole 128-byte lines per stored fp32 row piece (the last strip may be shorter)
   g->nstrips = (int)((oW + 63) / 64);
@@ -396,14 +440,15 @@ bool f32_geometry(int dtype, int64_t W, const aa_axis &aw, F32Geometry *g) {
 
 bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah,
                                     const aa_axis *aw) {
-  if ((dtype != AA_F32 && dtype != AA_F16 && dtype != AA_BF16) || layout != AA_NCHW) return false;
+  if (dtype != AA_F32 && dtype != AA_F16 && dtype != AA_BF16) return false;
+  if (layout != AA_NCHW && layout != AA_NHWC) return false;
   if (!ah || !aw || ah->kind != AA_TABLE_F32 || aw->kind != AA_TABLE_F32) return false;
   if (ah->scatter_off <= 0 || ah->scatter_max <= 0 || ah->scatter_max > 6) return false;
   if (H < ah->out_size) return false;
   F32Geometry g;
-  if (!f32_geometry(dtype, W, *aw, &g)) return false;
-  if ((uint64_t)H * W * 4 > 0xFFFFFFF0ull) return false;
-  if ((uint64_t)ah->out_size * aw->out_size * 4 > 0xFFFFFFF0ull) return false;
+  if (!f32_geometry(dtype, layout, C, W, *aw, &g)) return false;
+  if ((uint64_t)H * W * 4 * g.cs > 0xFFFFFFF0ull) return false;
+  if ((uint64_t)ah->out_size * aw->out_size * 4 * g.cs > 0xFFFFFFF0ull) return false;
   if (!aa_grid_fits(N * C * g.nstrips)) return false;
   return true;
 }
@@ -413,15 +458,17 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
   const int es = q.dtype == AA_F32 ? 4 : 2;
   if (((uintptr_t)q.out & (es - 1)) != 0 || ((uintptr_t)q.in & (es - 1)) != 0) return 0;
   F32Geometry g;
-  f32_geometry(q.dtype, q.W, q.aw, &g);
+  f32_geometry(q.dtype, q.layout, q.C, q.W, q.aw, &g);
 
   FusedF32Params p;
-  p.H = (int)q.H; p.W = (int)q.W; p.oH = (int)q.oH; p.oW = (int)q.oW;
+  p.H = (int)q.H; p.W = (int)q.W * g.cs; p.oH = (int)q.oH; p.oW = (int)q.oW * g.cs;
+  p.Wp = (int)q.W; p.oWp = (int)q.oW;
   p.ksize_w = q.aw.ksize; p.ksize_h = q.ah.ksize;
-  p.plane_in_bytes = (unsigned long long)q.H * q.W * es;
-  p.plane_out_bytes = (unsigned long long)q.oH * q.oW * es;
-  p.total_in_bytes = p.plane_in_bytes * (unsigned long long)(q.N * q.C);
-  p.total_out_bytes = p.plane_out_bytes * (unsigned long long)(q.N * q.C);
+  p.plane_in_bytes = (unsigned long long)q.H * q.W * es * (g.cs == 1 ? 1 : q.C);
+  p.plane_out_bytes = (unsigned long long)q.oH * q.oW * es * (g.cs == 1 ? 1 : q.C);
+  const unsigned long long planes = (unsigned long long)(g.cs == 1 ? q.N * q.C : q.N);
+  p.total_in_bytes = p.plane_in_bytes * planes;
+  p.total_out_bytes = p.plane_out_bytes * planes;
   p.sc_off = q.ah.scatter_off;
   p.nstrips = g.nstrips;
   p.strip_w = g.strip_w;
@@ -433,7 +480,9 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
 
   int rc = 0;
   const int mc = q.ah.scatter_max;
-  if (q.dtype == AA_F32) {
+  if (g.cs == 3) rc = launch_interleaved<3>(g.nq, mc, p, q);
+  else if (g.cs == 4) rc = launch_interleaved<4>(g.nq, mc, p, q);
+  else if (q.dtype == AA_F32) {
     switch (g.nq) {
       case 2: rc = launch_q<2, AA_F32>(mc, p, q); break;
       case 3: rc = launch_q<3, AA_F32>(mc, p, q); break;
@@ -446,6 +495,7 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
   } else {
     rc = g.nq == 2 ? launch_q<2, AA_BF16>(mc, p, q) : launch_q<3, AA_BF16>(mc, p, q);
   }
-  if (rc == 1) *variant = q.dtype == AA_F32 ? "fused_f32_nchw" : (q.dtype == AA_F16 ? "fused_f16_nchw" : "fused_bf16_nchw");
+  if (rc == 1 && g.cs != 1) *variant = "fused_f32_nhwc";
+  else if (rc == 1) *variant = q.dtype == AA_F32 ? "fused_f32_nchw" : (q.dtype == AA_F16 ? "fused_f16_nchw" : "fused_bf16_nchw");
   return rc;
 }
