@@ -25,7 +25,6 @@ static bool v3_shape_ok(int dtype, int layout, int64_t N, int64_t Cin, int64_t H
   int tw = round_tw(taps_w);
   if (flt && tw != 0 && tw < 6) tw = 6;  // the float variant is instantiated for windows of 6, 8 and 12 taps
   if (tw == 0 || W < tw) return false;
-  if ((oW * C) % 4 != 0 || (C == 3 && oW % 4 != 0)) return false;
   if ((uint64_t)H * W * C > 0xFFFFFFF0ull || (uint64_t)oH * oW * C > 0xFFFFFFF0ull) return false;
   const int span_px = aa_strip_span_px(aw, tw);
   if (span_px < 0) return false;
@@ -50,7 +49,6 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   if (!v3_shape_ok(q.dtype, q.layout, q.N, q.C, q.H, q.W, q.ah, q.aw, &flt, &planar, &tw, q.out_f32, q.out_layout)) return 0;
   const int C = planar ? 1 : (int)q.C;
   const int64_t NI = planar ? q.N * q.C : q.N;  // images the kernel sees
-  if (((uintptr_t)q.out & 3) != 0) return 0;
   const int G = aa_v3_group();
 
   FusedU8V3Params p;
@@ -61,6 +59,8 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   p.outm = q.out_f32 ? (planar || q.out_layout == AA_NCHW ? 1 : 2) : 0;
   p.normalize = q.out_f32 ? q.normalize : 0;
   p.cin = (int)q.C;
+  p.byte_store = (!q.out_f32 && ((q.oW * C) % 4 != 0 || (C == 3 && q.oW % 4 != 0) || ((uintptr_t)q.out & 3) != 0)) ? 1 : 0;
+  if (q.out_f32 && ((uintptr_t)q.out & 3) != 0) return AA_ERR_BAD_SHAPE;  // a float tensor that is not float aligned
   for (int c = 0; c < 4; c++) { p.mean[c] = q.mean[c]; p.std[c] = q.std[c]; }
   p.in_mis = (int)((uintptr_t)q.in & 15);
   p.total_in_bytes = p.img_in_bytes * (unsigned long long)NI + (unsigned long long)p.in_mis;

@@ -80,6 +80,8 @@ struct FusedU8V3Params {
   // byte(): what np.asarray(pil) -> transpose -> .float() -> op gives (test.py:337-339,55), optionally (v - mean) / std
   int outm, normalize, cin;
   float mean[4], std[4];
+  int byte_store;  // output rows that are not whole dwords (oW*C % 4 != 0, or C == 3 with oW % 4 != 0) or an output pointer that
+                   // is not dword aligned: every lane stores its own bytes instead of the quad-merged dword stores
 };
 
 namespace {
@@ -339,6 +341,14 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
         }
         stored = true;
       }
+    }
+    if (!stored && p.byte_store) {  // (wave-uniform) ragged rows: C byte stores per lane
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        const unsigned b = FLT ? trunc8(A[0][c]) : (unsigned)clip8_int(A[0][c]);
+        if (active) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, (unsigned)((ox0 + lane) * C + c), (unsigned)oy * out_row_bytes, 0);
+      }
+      stored = true;
     }
     if (stored) {
     } else if constexpr (C == 3) {

@@ -344,12 +344,15 @@ def test_fused_kernels_match_generic_at_full_size(aa):
               (harness(aa.nearest_forward), x8[:8], [196, 320]), (harness(aa.linear_forward), x8t[:4], [320, 196]),
               (harness(aa.cubic_forward), x4, [150, 252]), (harness(aa.linear_forward), x8[:2], [438, 320]),
               (harness(aa.linear_forward), x8p[:4], [196, 320]), (harness(aa.cubic_forward), x8p[:2], [196, 320])]  # test.py's layout
+    # rows that are not whole dwords (oW % 4 != 0): byte stores, still one launch
+    cases += [(aa.linear_forward, x8[:3], [196, 322]), (aa.cubic_forward, x8[:3], [200, 402]), (harness(aa.linear_forward), x8[:3], [196, 323]),
+              (aa.linear_forward, x4[:2], [111, 203]), (aa.linear_forward, x8p[:2], [196, 321])]
     xw = torch.randint(0, 256, (2, 120, 1700, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)  # wide: 10 strips, short last group
     cases += [(aa.linear_forward, xw, [60, 600]), (harness(aa.linear_forward), xw, [60, 600]), (aa.linear_forward, xw.contiguous(), [60, 600])]
     xf = torch.rand(6, 3, 438, 906, device="cuda") * 255
     cases += [(aa.linear_forward, xf, [196, 320]), (aa.cubic_forward, xf, [196, 320]), (aa.nearest_forward, xf, [196, 320])]
     xfl = xf.contiguous(memory_format=torch.channels_last)                                              # fp32 channels_last (s2.2:752)
-    cases += [(aa.linear_forward, xfl, [196, 320]), (aa.cubic_forward, xfl, [196, 320]), (aa.nearest_forward, xfl[:2], [100, 129])]
+    cases += [(aa.linear_forward, xfl, [196, 320]), (aa.cubic_forward, xfl, [196, 320]), (aa.nearest_forward, xfl[:2], [200, 300])]
     xf4 = (torch.rand(2, 4, 300, 500, device="cuda") - 0.3).contiguous(memory_format=torch.channels_last)
     cases += [(aa.linear_forward, xf4, [111, 204]), (aa.cubic_forward, xf4, [150, 251])]
     xc = torch.rand(3, 3, 1024, 1024, device="cuda") * 255                                              # config 2 shape
@@ -369,6 +372,7 @@ def test_fused_kernels_match_generic_at_full_size(aa):
             _lib.set_fused(1)
             y1 = fn(x, size)
             fused_seen.add(_lib.last_variant())
+            assert _lib.last_variant().startswith("fused"), (_lib.last_variant(), getattr(fn, "__name__", "?"), tuple(x.shape), size)
             _lib.set_fused(0)
             y0 = fn(x, size)
             assert _lib.last_variant().startswith("generic"), _lib.last_variant()
