@@ -314,6 +314,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     if constexpr (FLT) {
       if (p.outm != 0) {  // (wave-uniform) float32 output: the accumulators themselves, one 256-byte row piece per plane
         float v[C];
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // (address arithmetic of this path stays inside it, see the byte-store path)
 #pragma unroll
         for (int c = 0; c < C; c++) {
           v[c] = __int_as_float(A[0][c]);
@@ -323,10 +325,10 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
           for (int c = 0; c < C; c++)
             if (active)
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[c]), orsrc, (unsigned)(ox0 + lane) * 4u,
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[c]), orsrc, (unsigned)(ox0 + lane_o) * 4u,
                                                     ((unsigned)c * (unsigned)p.oH + (unsigned)oy) * (unsigned)p.oW * 4u, 0);
         } else {
-          const unsigned fv = (unsigned)(ox0 + lane) * (unsigned)(4 * C), fs = (unsigned)oy * (unsigned)p.oW * (unsigned)(4 * C);
+          const unsigned fv = (unsigned)(ox0 + lane_o) * (unsigned)(4 * C), fs = (unsigned)oy * (unsigned)p.oW * (unsigned)(4 * C);
           if constexpr (C == 3) {
             typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
             const u32x3 t = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
@@ -343,10 +345,15 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       }
     }
     if (!stored && p.byte_store) {  // (wave-uniform) ragged rows: C byte stores per lane
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));  // keep this rare path's address arithmetic INSIDE it: hoisted out of the row loop it
+                                        // costs the common path 5 VGPRs, i.e. a wave per SIMD (76 -> 81 registers)
+      const unsigned bv = (unsigned)((ox0 + lane_o) * C);
+      const bool act = lane_o < bw;
 #pragma unroll
       for (int c = 0; c < C; c++) {
         const unsigned b = FLT ? trunc8(A[0][c]) : (unsigned)clip8_int(A[0][c]);
-        if (active) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, (unsigned)((ox0 + lane) * C + c), (unsigned)oy * out_row_bytes, 0);
+        if (act) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, bv + c, (unsigned)oy * out_row_bytes, 0);
       }
       stored = true;
     }
@@ -582,6 +589,9 @@ int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
   const size_t lds_blk = lds * spb;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   p.ybands = pick_ybands(p.n_images * sgroups, (double)aa_device_cu_count() * resident(spb), taps_h, q.H, q.oH);
+  if (getenv("AA_V3_DEBUG"))
+    fprintf(stderr, "[aa v3] strips %d spb %d (resident(1) %d, resident(%d) %d) ybands %d lds/strip %zu images %lld\n", p.nstrips, spb,
+            resident(1), p.nstrips <= 8 ? p.nstrips : 4, resident(p.nstrips <= 8 ? p.nstrips : 4), p.ybands, lds, (long long)p.n_images);
   const int64_t groups8 = (p.n_images * (int64_t)p.ybands + 7) / 8 * 8;  // whole rounds of the 8 XCDs (see the kernel)
   const int64_t grid = groups8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;

@@ -216,3 +216,30 @@ def test_bench_launcher_starts_n_ranks():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-dry-run"], capture_output=True,
                          text=True, timeout=300, env=env)
     assert out.returncode != 0 and "torch.distributed.run" in out.stderr
+
+
+def test_headline_kernel_keeps_six_waves_per_simd(tmp_path):
+    """Occupancy regression guard (no GPU needed: read from the built code object).  The headline kernel — uint8 channels_last,
+    3 channels, 6-tap windows, 2 open output rows, non-negative weights, periodic slot phases — must stay within 80 VGPRs
+    (6 waves per SIMD: single-strip workgroups fill 24 wave slots per CU).  At 81 the launch heuristic falls back to
+    5-strip workgroups and the bench loses ~8 % (round 2: an innocent emit branch hoisted its address arithmetic)."""
+    import shutil
+
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    obj = os.path.join(ROOT, "interpolate_antialiasing_amd", "csrc", "aa_fused_u8_v3_c3.o")
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(obj)):
+        pytest.skip("needs the ROCm LLVM tools and the built object")
+    local = tmp_path / "c3.o"
+    shutil.copy(obj, local)
+    subprocess.run([objdump, "--offloading", str(local)], check=True, capture_output=True, cwd=tmp_path)
+    cos = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert cos, os.listdir(tmp_path)
+    notes = subprocess.run([readelf, "--notes", str(tmp_path / cos[0])], check=True, capture_output=True, text=True).stdout
+    m = re.search(r"\.name:\s+\S*fused_u8_nhwc_v3_kernelILi3ELi6ELi8ELb0ELi2ELb1ELb1ELb0E\S*\n(?:.*\n){0,40}?\s+\.vgpr_count:\s+(\d+)", notes)
+    if m is None:  # field order differs: search backwards as well
+        blocks = notes.split("- .agpr_count")
+        hit = [b for b in blocks if "fused_u8_nhwc_v3_kernelILi3ELi6ELi8ELb0ELi2ELb1ELb1ELb0E" in b]
+        assert hit, "headline kernel not found in the code object"
+        m = re.search(r"\.vgpr_count:\s+(\d+)", hit[0])
+    assert m is not None
+    assert int(m.group(1)) <= 80, f"headline kernel uses {m.group(1)} VGPRs (> 80: 5 waves per SIMD)"

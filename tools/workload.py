@@ -21,6 +21,12 @@ elif name == "c2":
 elif name == "c0f32":
     x = torch.rand(256, 3, 438, 906, device=dev) * 255
     fn = lambda: aa.linear_forward(x, [196, 320])
+elif name == "c0nhwc":
+    x = (torch.rand(256, 3, 438, 906, device=dev) * 255).contiguous(memory_format=torch.channels_last)
+    fn = lambda: aa.linear_forward(x, [196, 320])
+elif name == "c2f16":
+    x = (torch.rand(64, 3, 1024, 1024, device=dev) * 255).half()
+    fn = lambda: aa.linear_forward(x, [224, 224])
 elif name == "shard3":
     x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
     fn = lambda: aa.linear_forward(x, [320, 196])
