@@ -776,3 +776,32 @@ def test_u8_to_float_conversion_fused(aa, golden_kat):
         aa.linear_forward(hwc.float(), [196, 320], out_dtype=torch.float32)
     with pytest.raises(NotImplementedError):
         aa.linear_forward(hwc, [196, 320], out_dtype=torch.float32, uint8_mode="pil")
+
+
+# ------------------------------------------------------------------------------------------------ the reference-side binding
+def test_integration_stub_matches_the_shim(aa):
+    """INTEGRATION.md's pybind11 module (tools/integration_stub/extension_interpolate_amd.cpp: the reference's four callables
+    with their bodies replaced by C-ABI calls) really compiles against the installed PyTorch and gives the shim's results bit
+    for bit: uint8 channels_last (Pillow-exact), fp32 NCHW and channels_last, bicubic, box, and the true-adjoint backward."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "integration_stub", "build.py")
+    spec = importlib.util.spec_from_file_location("aa_stub_build", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    stub = mod.build()
+    torch.manual_seed(31)
+    x8 = torch.randint(0, 256, (3, 438, 906, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
+    xf = torch.rand(2, 3, 438, 906, device="cuda") * 255
+    for x in (x8, xf, xf.contiguous(memory_format=torch.channels_last), xf.double()[:1]):
+        for name in ("linear_forward", "cubic_forward", "nearest_forward"):
+            y = getattr(stub, name)(x, [196, 320])
+            z = getattr(aa, name)(x, [196, 320])
+            assert y.dtype == z.dtype and y.stride() == z.stride() and torch.equal(y, z), (name, x.dtype)
+    exp = oracle.pil_resize_u8("linear", x8[:1].cpu().numpy(), (196, 320))
+    assert np.array_equal(stub.linear_forward(x8[:1], [196, 320], False).cpu().numpy(), exp)
+    g = torch.randn(2, 3, 196, 320, device="cuda")
+    assert torch.equal(stub.linear_backward(g, [196, 320], [2, 3, 438, 906], False), aa.linear_backward(g, [196, 320], [2, 3, 438, 906]))
+    with pytest.raises(RuntimeError, match="It is expected output_size equals to 2"):
+        stub.linear_forward(xf, [4, 4, 4])
