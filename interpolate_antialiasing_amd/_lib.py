@@ -36,7 +36,7 @@ class TableHeader(ctypes.Structure):
         ("magic", ctypes.c_int32), ("filter", ctypes.c_int32), ("kind", ctypes.c_int32), ("in_size", ctypes.c_int32),
         ("out_size", ctypes.c_int32), ("ksize", ctypes.c_int32), ("align_corners", ctypes.c_int32),
         ("max_taps", ctypes.c_int32), ("transposed", ctypes.c_int32), ("scatter_off", ctypes.c_int32),
-        ("scatter_ksize", ctypes.c_int32), ("scatter_max", ctypes.c_int32), ("span64p1", ctypes.c_int32), ("span4p1", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
+        ("scatter_ksize", ctypes.c_int32), ("scatter_max", ctypes.c_int32), ("span64p1", ctypes.c_int32), ("span4p1", ctypes.c_int32), ("gather_off", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1),
     ]
 
 
@@ -45,7 +45,7 @@ class Axis(ctypes.Structure):
         ("table_dev", ctypes.c_void_p), ("in_size", ctypes.c_int32), ("out_size", ctypes.c_int32),
         ("ksize", ctypes.c_int32), ("max_taps", ctypes.c_int32), ("kind", ctypes.c_int32), ("filter", ctypes.c_int32),
         ("scatter_off", ctypes.c_int32), ("scatter_ksize", ctypes.c_int32), ("scatter_max", ctypes.c_int32),
-        ("span64p1", ctypes.c_int32), ("span4p1", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
+        ("span64p1", ctypes.c_int32), ("span4p1", ctypes.c_int32), ("gather_off", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
     ]
 
 

@@ -17,8 +17,15 @@ __host__ __device__ inline size_t aa_table_xsize_off(int64_t out) { return sizeo
 __host__ __device__ inline size_t aa_table_w_off(int64_t out) {
   return aa_align16(sizeof(aa_table_header) + 8 * (size_t)out);
 }
-__host__ __device__ inline size_t aa_table_total_bytes(int kind, int64_t out, int ksize) {
+// end of the weight rows = start of the gather section
+__host__ __device__ inline size_t aa_table_weights_end(int kind, int64_t out, int ksize) {
   return aa_align16(aa_table_w_off(out) + (size_t)out * (size_t)ksize * aa_weight_elem_bytes(kind));
+}
+// gather section (AA_TABLE_F32 tables, forward and transposed): one 32-byte record per OUTPUT index
+// {xmin, xsize, w[0..5]} — a table row in one scalar load for kernels whose vertical pass gathers (aa_fused_float_up.hip)
+__host__ __device__ inline size_t aa_table_gather_bytes(int kind, int64_t out) { return kind == AA_TABLE_F32 ? 32 * (size_t)out : 0; }
+__host__ __device__ inline size_t aa_table_total_bytes(int kind, int64_t out, int ksize) {
+  return aa_table_weights_end(kind, out, ksize) + aa_table_gather_bytes(kind, out);
 }
 
 template <typename WT>

@@ -32,6 +32,14 @@
 
 #include "aa_common.h"
 
+#ifndef AA_UP_G
+#define AA_UP_G 8  // staged input rows per wave
+#endif
+#ifndef AA_UP_ABL
+#define AA_UP_ABL 0  // developer ablations (wrong results): 1 no output stores, 2 no input (no DMA, no horizontal pass), 3 stores
+                     // of every output row land on row 0 (stay in cache)
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -41,6 +49,7 @@ struct FusedF32UpParams {
   int ksize_w, ksize_h;
   int ybands, nstrips, strips_per_block, strip_w;
   int nseg, seg_bytes;
+  int gather_off;  // gather section of the H table: one 32-byte record {ymin, ysize, w[6]} per output row
   unsigned long long plane_in_bytes, plane_out_bytes, total_in_bytes, total_out_bytes;
   long long n_groups;  // (plane, band) groups = planes * ybands
 };
@@ -177,7 +186,7 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   int dma_next = r_begin;  // next input row to stage
   int slot_next = 0;       // its slot
   for (int i = 0; i < G; i++) {
-    if (dma_next < r_stop) {
+    if (AA_UP_ABL != 2 && dma_next < r_stop) {
       dma(dma_next, slot_next);
       dma_next++;
       slot_next = slot_next + 1 == G ? 0 : slot_next + 1;
@@ -227,17 +236,18 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
     slot_top = slot_top + 1 == G ? 0 : slot_top + 1;
   };
 
-  // table row of an output: window start, length, weights (wave-uniform, loaded one output row ahead)
+  // table row of an output: window start, length, weights — ONE scalar load of the row's gather record (wave-uniform,
+  // issued one output row ahead)
   struct VRow { int m; int s; float w[KR]; };
+  const int32_t *__restrict__ grec = (const int32_t *)(tab_h + p.gather_off);
   auto load_vrow = [&](int oy) -> VRow {
     VRow v;
     const int o = oy < p.oH ? oy : p.oH - 1;
-    v.m = __builtin_amdgcn_readfirstlane(ymin_h[o]);
-    v.s = __builtin_amdgcn_readfirstlane(ysize_h[o]);
-    const float *wr = kh + (size_t)o * p.ksize_h;
+    const int32_t *rec = (const int32_t *)((const char *)grec + (unsigned)o * 32u);
+    v.m = __builtin_amdgcn_readfirstlane(rec[0]);
+    v.s = __builtin_amdgcn_readfirstlane(rec[1]);
 #pragma unroll
-    for (int k2 = 0; k2 < KR; k2++)  // rows are zero padded to ksize_h; never read past the row
-      v.w[k2] = (k2 < p.ksize_h) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wr[k2]))) : 0.0f;
+    for (int k2 = 0; k2 < KR; k2++) v.w[k2] = __int_as_float(__builtin_amdgcn_readfirstlane(rec[2 + k2]));
     return v;
   };
 
@@ -247,7 +257,7 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
     int s = cur.s > 1 ? cur.s : 1;
     s = s < KR ? s : KR;
     const int need = cur.m + s;
-    while (top < need) hpass_row();
+    if (AA_UP_ABL != 2) { while (top < need) hpass_row(); }
     // Windows end at non-decreasing rows and the ring was advanced exactly to this one's end (top == need), so the
     // window's rows m .. m+s-1 are the ring's LAST s entries: ring[KR-s .. KR-1].
     float res[CPL];
@@ -265,15 +275,15 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
         }
       }
     }
-    const unsigned soff = (unsigned)oy * out_row_bytes;
+    const unsigned soff = AA_UP_ABL == 3 ? 0u : (unsigned)oy * out_row_bytes;
     // vm_issued may only count instructions that are certainly issued (an all-lanes-off store is branched around): every
     // count below is guarded by a wave-uniform condition under which lane 0 or the ragged lane really stores
     if constexpr (CPL == 4) {
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const u32x4 t = {__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
       if (bw >= CPL) {
-        if (full_lane) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 0);
-        vm_issued++;
+        if (full_lane && (AA_UP_ABL != 1 || t.x == 0x12345678u)) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 0);
+        if (AA_UP_ABL != 1) vm_issued++;
       }
     } else if constexpr (CPL == 2) {
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -290,7 +300,7 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
       const int ragged = bw % CPL;  // (wave-uniform) columns of the strip's last, partial lane: stored one by one
 #pragma unroll
       for (int e = 0; e < CPL - 1; e++) {
-        if (e < ragged) {
+        if (__builtin_expect(ragged != 0, 0) && e < ragged) {
           if (col0 == bw - ragged) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[e]), orsrc, store_voff + 4u * e, soff, 0);
           vm_issued++;
         }
@@ -355,9 +365,9 @@ int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
 
 template <int U, int CPL>
 int launch_kr(int kr, const FusedF32UpParams &p, const AAProblem &q, size_t lds) {
-  if (kr <= 2) return launch_k<U, 8, 2, CPL>(p, q, lds);
-  if (kr <= 4) return launch_k<U, 8, 4, CPL>(p, q, lds);
-  return launch_k<U, 8, 8, CPL>(p, q, lds);
+  if (kr <= 2) return launch_k<U, AA_UP_G, 2, CPL>(p, q, lds);
+  if (kr <= 4) return launch_k<U, AA_UP_G, 4, CPL>(p, q, lds);
+  return launch_k<U, AA_UP_G, 6, CPL>(p, q, lds);
 }
 
 // Columns per lane and union width: the widest CPL whose CPL * U lane masks fit the scalar registers (<= 20) and whose
@@ -400,7 +410,7 @@ bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t N, int64_t
   if (!ah || !aw || ah->kind != AA_TABLE_F32 || aw->kind != AA_TABLE_F32) return false;
   if (H > ah->out_size) return false;  // shrinking heights: aa_fused_float.hip
   const int taps_h = ah->max_taps > 0 ? ah->max_taps : ah->ksize;
-  if (taps_h > 8) return false;
+  if (taps_h > 6 || ah->gather_off <= 0) return false;  // (a gather record holds 6 weights)
   UpGeometry g;
   if (!up_geometry(W, *aw, &g)) return false;
   if ((uint64_t)H * W * 4 > 0xFFFFFFF0ull || (uint64_t)ah->out_size * aw->out_size * 4 > 0xFFFFFFF0ull) return false;
@@ -427,9 +437,10 @@ int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   p.strips_per_block = p.nstrips <= 8 ? p.nstrips : 4;
   p.nseg = g.nseg;
   p.seg_bytes = p.nseg * 16;
+  p.gather_off = q.ah.gather_off;
   p.ybands = 1;
   p.n_groups = 0;
-  const size_t lds = (size_t)8 * p.seg_bytes;
+  const size_t lds = (size_t)AA_UP_G * p.seg_bytes;
 
   int rc = 0;
 #define AA_UP_CASE(UU, CC) if (g.u == UU && g.cpl == CC) rc = launch_kr<UU, CC>(taps_h, p, q, lds)

@@ -169,6 +169,19 @@ __global__ void table_span_kernel(char *table, int out_size) {
   atomicMax(&((aa_table_header *)table)->span4p1, d4 + 1);
 }
 
+// gather section: record i = {xmin[i], xsize[i], w[i][0..5]} (weights beyond ksize are 0): one scalar load per output row
+__global__ void table_gather_kernel(char *table, int out_size, int ksize, int gather_off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= out_size) return;
+  const int32_t *xmin = (const int32_t *)(table + aa_table_xmin_off());
+  const int32_t *xsize = (const int32_t *)(table + aa_table_xsize_off(out_size));
+  const int32_t *w = (const int32_t *)(table + aa_table_w_off(out_size)) + (size_t)i * ksize;  // float bits
+  int32_t *rec = (int32_t *)(table + gather_off) + (size_t)i * 8;
+  rec[0] = xmin[i];
+  rec[1] = xsize[i];
+  for (int k = 0; k < 6; k++) rec[2 + k] = k < ksize ? w[k] : 0;
+}
+
 __global__ void table_write_header(aa_table_header h, char *table) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *(aa_table_header *)table = h;
 }
@@ -270,6 +283,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
   h.scatter_max = 0;
   h.span64p1 = 0;
   h.span4p1 = 0;
+  h.gather_off = kind == AA_TABLE_F32 ? (int32_t)aa_table_weights_end(kind, out_size, ksize) : 0;
   if ((kind == AA_TABLE_PIL || kind == AA_TABLE_F32) && scatter_ksize > 0) {
     h.scatter_off = (int32_t)aa_table_total_bytes(kind, out_size, ksize);
     h.scatter_ksize = scatter_ksize;
@@ -303,6 +317,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
     }
   }
   hipLaunchKernelGGL(table_span_kernel, dim3(blocks), dim3(threads), 0, stream, t, (int)out_size);
+  if (h.gather_off) hipLaunchKernelGGL(table_gather_kernel, dim3(blocks), dim3(threads), 0, stream, t, (int)out_size, ksize, h.gather_off);
   AA_HIP_CHECK_LAUNCH();
   return AA_OK;
 }
@@ -320,6 +335,7 @@ int aa_launch_table_transpose(const aa_table_header &fh, const void *table_dev, 
   h.scatter_max = 0;
   h.span64p1 = 0;
   h.span4p1 = 0;
+  h.gather_off = fh.kind == AA_TABLE_F32 ? (int32_t)aa_table_weights_end(fh.kind, fh.in_size, tr_ksize) : 0;
   char *t = (char *)tr_dev;
   hipLaunchKernelGGL(table_write_header, dim3(1), dim3(64), 0, stream, h, t);
   const int threads = 128;
@@ -337,6 +353,7 @@ int aa_launch_table_transpose(const aa_table_header &fh, const void *table_dev, 
     return AA_ERR_BAD_DTYPE;
   }
   hipLaunchKernelGGL(table_span_kernel, dim3(blocks), dim3(threads), 0, stream, t, fh.in_size);
+  if (h.gather_off) hipLaunchKernelGGL(table_gather_kernel, dim3(blocks), dim3(threads), 0, stream, t, fh.in_size, tr_ksize, h.gather_off);
   AA_HIP_CHECK_LAUNCH();
   return AA_OK;
 }

@@ -22,7 +22,7 @@ KIND_IDS = {"pil": _lib.TABLE_PIL, "f32": _lib.TABLE_F32, "f64": _lib.TABLE_F64}
 HEADER_BYTES = ctypes.sizeof(_lib.TableHeader)  # 64
 
 # fixed-length int64 descriptor broadcast ahead of the payload so receivers can allocate
-META_LEN = 15
+META_LEN = 16
 
 
 def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
@@ -47,18 +47,19 @@ class WeightTable:
     scatter_max: int = 0
     span64p1: int = 0  # 1 + the widest spread of 64 consecutive outputs' window starts (measured on device; 0 = unknown)
     span4p1: int = 0   # the same over 4 consecutive outputs
+    gather_off: int = 0  # byte offset of the per-output gather records (F32 tables)
 
     def axis(self) -> _lib.Axis:
         if not self.buf.is_cuda:
             raise _lib.AAInterpError("weight table is not on a GPU")
         return _lib.Axis(ctypes.c_void_p(self.buf.data_ptr()), self.in_size, self.out_size, self.ksize, self.max_taps,
-                         self.kind, self.filter, self.scatter_off, self.scatter_ksize, self.scatter_max, self.span64p1, self.span4p1)
+                         self.kind, self.filter, self.scatter_off, self.scatter_ksize, self.scatter_max, self.span64p1, self.span4p1, self.gather_off)
 
     # ---- transport -----------------------------------------------------------------------------------
     def meta(self) -> torch.Tensor:
         return torch.tensor([0x42544141, self.filter, self.kind, self.in_size, self.out_size, self.ksize,
                              self.max_taps, int(self.align_corners), int(self.transposed), self.buf.numel(),
-                             self.scatter_off, self.scatter_ksize, self.scatter_max, self.span64p1, self.span4p1],
+                             self.scatter_off, self.scatter_ksize, self.scatter_max, self.span64p1, self.span4p1, self.gather_off],
                             dtype=torch.int64)
 
     @staticmethod
@@ -70,7 +71,7 @@ class WeightTable:
             raise _lib.AAInterpError("weight-table payload size mismatch")
         return WeightTable(buf=buf, filter=m[1], kind=m[2], in_size=m[3], out_size=m[4], ksize=m[5], max_taps=m[6],
                            align_corners=bool(m[7]), transposed=bool(m[8]), scatter_off=m[10], scatter_ksize=m[11],
-                           scatter_max=m[12], span64p1=m[13], span4p1=m[14])
+                           scatter_max=m[12], span64p1=m[13], span4p1=m[14], gather_off=m[15])
 
     # ---- inspection (tests) ----------------------------------------------------------------------------
     def unpack_scatter(self):
@@ -130,7 +131,7 @@ def build_table(filter_id: int, kind: int, in_size: int, out_size: int, align_co
         hdr = _lib.TableHeader()
         _lib.check(L.aa_table_query(ctypes.c_void_p(buf.data_ptr()), ctypes.byref(hdr), s), "aa_table_query")
     return WeightTable(buf, filter_id, kind, in_size, out_size, k, int(hdr.max_taps), bool(align_corners), False,
-                       int(hdr.scatter_off), int(hdr.scatter_ksize), int(hdr.scatter_max), int(hdr.span64p1), int(hdr.span4p1))
+                       int(hdr.scatter_off), int(hdr.scatter_ksize), int(hdr.scatter_max), int(hdr.span64p1), int(hdr.span4p1), int(hdr.gather_off))
 
 
 def get_table(filter_id: int, kind: int, in_size: int, out_size: int, align_corners: bool = False, scale: float = 0.0,
@@ -173,7 +174,7 @@ def get_transposed_table(fwd: WeightTable, scale: float = 0.0) -> WeightTable:
         hdr = _lib.TableHeader()
         _lib.check(L.aa_table_query(ctypes.c_void_p(buf.data_ptr()), ctypes.byref(hdr), s), "aa_table_query")
     t = WeightTable(buf, fwd.filter, fwd.kind, fwd.out_size, fwd.in_size, tk, int(hdr.max_taps), fwd.align_corners, True,
-                    span64p1=int(hdr.span64p1), span4p1=int(hdr.span4p1))
+                    span64p1=int(hdr.span64p1), span4p1=int(hdr.span4p1), gather_off=int(hdr.gather_off))
     with _cache_lock:
         _cache[key] = t
     return t

@@ -54,7 +54,7 @@ const Table &get_table(int filter, int kind, int64_t in, int64_t out, bool align
     TORCH_CHECK(rc == AA_OK, aa_strerror(rc));
   }
   t.axis = aa_axis{t.buf.data_ptr(), h.in_size,  h.out_size,      h.ksize,       h.max_taps, h.kind,
-                   h.filter,         h.scatter_off, h.scatter_ksize, h.scatter_max, h.span64p1, h.span4p1, {0, 0, 0}};
+                   h.filter,         h.scatter_off, h.scatter_ksize, h.scatter_max, h.span64p1, h.span4p1, h.gather_off, {0, 0}};
   return cache.emplace(key, std::move(t)).first->second;
 }
 
