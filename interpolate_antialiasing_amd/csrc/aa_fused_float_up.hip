@@ -113,7 +113,6 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   const float *__restrict__ kw = (const float *)(tab_w + aa_table_w_off(p.oW));
   const int32_t *__restrict__ ymin_h = (const int32_t *)(tab_h + aa_table_xmin_off());
   const int32_t *__restrict__ ysize_h = (const int32_t *)(tab_h + aa_table_xsize_off(p.oH));
-  const float *__restrict__ kh = (const float *)(tab_h + aa_table_w_off(p.oH));
 
   const int r_begin = __builtin_amdgcn_readfirstlane(ymin_h[oy0]);
   const int ylm = __builtin_amdgcn_readfirstlane(ymin_h[oy1 - 1]);
