@@ -6,7 +6,7 @@ TAG=$1; WL=$2
 export TMPDIR=/tmp
 cd /tmp
 mkdir -p $R/gpurun_out/pmc_$TAG
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pmc_$TAG/stats -- python3 $R/tools/workload.py $WL 30 > $R/gpurun_out/pmc_$TAG/log0.txt 2>&1 || echo "stats pass failed"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/pmc_$TAG/stats -- python3 $R/tools/workload.py $WL 600 > $R/gpurun_out/pmc_$TAG/log0.txt 2>&1 || echo "stats pass failed"
 i=0
 for CNT in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_VMEM_TA_ADDR_FIFO_FULL SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
