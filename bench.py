@@ -143,14 +143,21 @@ def cpu_baseline(seconds: float = 12.0):
             if dt >= budget:
                 return dt / n, n
 
-    t_u8, n_u8 = timeit(run_u8, seconds * 0.5)
-    t_f32, n_f32 = timeit(run_f32, seconds * 0.5)
+    t_u8, n_u8 = timeit(run_u8, seconds * 0.4)
+    t_f32, n_f32 = timeit(run_f32, seconds * 0.4)
+    t_one = None
+    if ref is not None:  # "at 1 thread and at all host cores"
+        torch.set_num_threads(1)
+        t_one, _ = timeit(run_u8, seconds * 0.2)
+        torch.set_num_threads(cores)
     return {
         "value": round(mpix / t_u8, 2), "unit": "Mpix/s", "cores": cores, "kind": kind,
         "sample": (f"step_three -DUSE_SEPARABLE_KERNEL forward, [1,3,438,906]->[196,320] bilinear AA, uint8 via "
-                   f"float()/byte() as test.py does, {n_u8} calls in {seconds * 0.5:.0f}s, {cores} threads; "
-                   f"fp32-only: {mpix / t_f32:.1f} Mpix/s ({n_f32} calls)"),
+                   f"float()/byte() as test.py does, {n_u8} calls in {seconds * 0.4:.0f}s, {cores} threads; "
+                   f"fp32-only: {mpix / t_f32:.1f} Mpix/s ({n_f32} calls)"
+                   + (f"; 1 thread: {mpix / t_one:.1f} Mpix/s" if t_one else "")),
         "us_per_image": round(t_u8 * 1e6, 1), "f32_value": round(mpix / t_f32, 2),
+        "value_1_thread": round(mpix / t_one, 2) if t_one else None,
     }
 
 
@@ -225,7 +232,7 @@ def secondary_configs(dev):
         with torch.cuda.graph(graph):
             aa.linear_forward(x1, [196, 320])
         ms = timed(graph.replay, reps=200)
-        res.append({"workload": "configs[1] as written, HIP-graph replay (latency)", "ms": round(ms, 4),
+        res.append({"workload": "configs[1] as written, HIP-graph replay (not a speed-up: hipGraphLaunch itself costs 10-16 us)", "ms": round(ms, 4),
                     "GB/s": round(3 * (438 * 906 + 196 * 320) / ms / 1e6, 1), "variant": "fused_u8_nhwc_pil_v3 (graph)"})
     except Exception as e:
         res.append({"workload": "configs[1] as written, HIP-graph replay (latency)", "error": str(e)[:200]})
