@@ -94,8 +94,7 @@ typedef struct aa_table_header {
  * { int32 first, int32 count | completes << 16, int32 w[6] }.  first = the first output whose window ends at or after
  * x; first .. first+count-1 = the outputs whose window holds x, w[k] = weight[first+k][x - xmin[first+k]] (zero
  * padded); completes = how many outputs, starting at `first`, have x as the LAST index of their window (they can be
- * emitted once x has been absorbed).  Present only when count <= 6 everywhere.  The in_size + 1 records are followed by a
- * compact 16-byte copy of each, { first, count | completes << 16, w[0], w[1] }, valid when scatter_max <= 2. */
+ * emitted once x has been absorbed).  Present only when count <= 6 everywhere. */
 
 /* Host-side description of one axis handed to the resample calls. */
 typedef struct aa_axis {

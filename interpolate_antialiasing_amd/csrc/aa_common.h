@@ -58,10 +58,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
                           int ksize, int scatter_ksize, void *table_dev, hipStream_t stream);
 // bytes of the scatter section appended to AA_TABLE_PIL tables (0 when scatter_ksize == 0)
 __host__ __device__ inline size_t aa_table_scatter_bytes(int64_t in_size, int scatter_ksize) {
-  // one 8-int record per input index + a sentinel, then a COMPACT copy {first, count | completes << 16, w[0], w[1]} of the
-  // same records (16 bytes each): when no input index feeds more than two outputs the kernels read that one — half the
-  // bytes per row, so a whole table of a few hundred rows stays in the scalar data cache
-  return scatter_ksize > 0 ? 48 * ((size_t)in_size + 1) : 0;
+  return scatter_ksize > 0 ? 32 * ((size_t)in_size + 1) : 0;  // one 8-int record per input index + a sentinel
 }
 int aa_launch_table_transpose(const aa_table_header &h, const void *table_dev, void *tr_dev, int tr_ksize,
                               hipStream_t stream);

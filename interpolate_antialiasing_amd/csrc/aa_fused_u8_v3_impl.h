@@ -297,10 +297,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   struct Scatter { int first; int cc; int w[MAXC]; };  // raw record words (nothing depends on them until they are used)
   auto load_scatter = [&](int r) -> Scatter {  // one 32-byte record: {first, count | completes << 16, w[6]}
     Scatter s;                                   // (the section has H + 1 records: r == H reads the all-zero sentinel)
-    if (AA_V3_ABL == 10) r = r_begin + ((r - r_begin) & 1);  // ablation: two records only (scalar-cache hits), wrong results
-    // (at most two outputs per input row: the compact 16-byte copy of the records, behind the 32-byte ones)
-    const int32_t *rec = MAXC == 2 ? (const int32_t *)((const char *)sc_rec + (unsigned)(p.H + 1) * 32u + (unsigned)r * 16u)
-                                   : (const int32_t *)((const char *)sc_rec + (unsigned)r * 32u);
+    const int32_t *rec = (const int32_t *)((const char *)sc_rec + (unsigned)r * 32u);
     s.first = __builtin_amdgcn_readfirstlane(rec[0]);
     s.cc = __builtin_amdgcn_readfirstlane(rec[1]);  // count | completes << 16
 #pragma unroll

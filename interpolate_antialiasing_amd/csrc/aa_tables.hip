@@ -261,8 +261,6 @@ __global__ void table_scatter_kernel(const char *fwd, int32_t *rec_all, int32_t 
     const int o = first + k;
     rec[2 + k] = (k < cnt) ? w[(size_t)o * ksize + (x - xmin[o])] : 0;
   }
-  int32_t *rec16 = rec_all + (size_t)(in_size + 1) * 8 + (size_t)x * 4;  // compact copy (valid when scatter_max <= 2)
-  rec16[0] = rec[0]; rec16[1] = rec[1]; rec16[2] = rec[2]; rec16[3] = rec[3];
   atomicMax(scatter_max, cnt > 1 ? cnt : 1);
 }
 
