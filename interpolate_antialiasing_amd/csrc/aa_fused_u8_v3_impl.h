@@ -126,8 +126,16 @@ __device__ inline void wait_vmcnt(int n) {  // rounding n DOWN only waits longer
 // FLT: the reference harness's uint8 semantics instead of Pillow's (AA_TABLE_F32 tables): bytes are converted to fp32,
 //      both passes run in fp32 with separately rounded product and sum in tap order (the intermediate is never rounded),
 //      the result is clamped to [0,255] and truncated (test.py:52-58,72,75).  Registers hold float bit patterns.
+#ifndef AA_V3_WAVES_PER_EU
+#define AA_V3_WAVES_PER_EU 0  // developer knob: force the register budget for this many waves per SIMD (0: compiler's choice)
+#endif
+#if AA_V3_WAVES_PER_EU
+#define AA_V3_OCC __attribute__((amdgpu_waves_per_eu(AA_V3_WAVES_PER_EU, AA_V3_WAVES_PER_EU)))
+#else
+#define AA_V3_OCC
+#endif
 template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC, bool FLT = false>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512) AA_V3_OCC
 fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const char *__restrict__ tab_w,
                         const char *__restrict__ tab_h, const FusedU8V3Params p) {
   constexpr int NV = (C * TW + 3) / 4;  // dwords holding one window
