@@ -673,11 +673,12 @@ int dispatch_tw(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, 
   if (tw <= 6) return launch<C, 6>(maxc, p, q, lds, grid);
   if (tw <= 8) return launch<C, 8>(maxc, p, q, lds, grid);
   if (tw <= 12) return launch<C, 12>(maxc, p, q, lds, grid);
+  if (tw <= 16) return launch<C, 16>(maxc, p, q, lds, grid);  // (bicubic thumbnails: 1750 -> 500 has 15 taps)
   return 0;
 }
 
 int round_tw(int taps) {
-  const int opts[] = {2, 4, 6, 8, 12};
+  const int opts[] = {2, 4, 6, 8, 12, 16};
   for (int o : opts)
     if (taps <= o) return o;
   return 0;

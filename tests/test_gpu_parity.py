@@ -712,8 +712,10 @@ def test_workspace_answer_matches_dispatch(aa):
     from interpolate_antialiasing_amd import _lib
 
     torch.manual_seed(12)
-    for fn, shape, size in ((aa.cubic_forward, (2, 1750, 1750, 3), [500, 500]), (aa.linear_forward, (1, 300, 2400, 3), [50, 400]),
-                            (aa.linear_forward, (1, 2400, 2400, 3), [400, 400]), (aa.cubic_forward, (1, 700, 1400, 4), [100, 200])):
+    for fn, shape, size, want in ((aa.cubic_forward, (2, 1750, 1750, 3), [500, 500], "fused_u8_nhwc_pil_v3"),     # 15 taps
+                                  (aa.linear_forward, (1, 300, 2400, 3), [50, 400], "fused_u8_nhwc_pil_v3"),      # 13 taps
+                                  (aa.linear_forward, (1, 2400, 2400, 3), [400, 400], "fused_u8_nhwc_pil_v3"),
+                                  (aa.cubic_forward, (1, 700, 1400, 4), [100, 200], "generic_2pass_u8_pil")):      # 29 taps: no fused kernel
         x = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
         y = fn(x, size)
         v = _lib.last_variant()
@@ -723,6 +725,7 @@ def test_workspace_answer_matches_dispatch(aa):
         finally:
             _lib.set_fused(1)
         assert torch.equal(y, y0), (shape, size, v)
+        assert v == want, (v, shape, size)  # 13-16 taps: the 16-tap window instantiation of the newest kernel
         exp = oracle.pil_resize_u8("cubic" if fn is aa.cubic_forward else "linear", x[:1].cpu().numpy(), tuple(size))
         assert np.array_equal(y[:1].cpu().numpy(), exp), (shape, size, v)
 
