@@ -191,6 +191,10 @@ def secondary_configs(dev):
     x = torch.rand(256, 3, 438, 906, device=dev) * 255
     add("configs[0] on GPU: fp32 NCHW [256,3,438,906]->[196,320] bilinear", lambda: aa.linear_forward(x, [196, 320]),
         256 * 3 * 4 * (438 * 906 + 196 * 320))
+    xd = x[:128].double()
+    add("fp64 NCHW [128,3,438,906]->[196,320] bilinear (the reference dispatches double too)", lambda: aa.linear_forward(xd, [196, 320]),
+        128 * 3 * 8 * (438 * 906 + 196 * 320))
+    del xd
     x = x.contiguous(memory_format=torch.channels_last)
     add("fp32 channels_last [256,3,438,906]->[196,320] bilinear", lambda: aa.linear_forward(x, [196, 320]),
         256 * 3 * 4 * (438 * 906 + 196 * 320))

@@ -132,13 +132,13 @@ static int scatter_ksize_for(int filter, int kind, int64_t in_size, int64_t out_
   (void)filter; (void)in_size; (void)out_size;
   // 32-bit weights only (a record holds 6).  Always present: whether an input index really feeds <= 6 outputs is
   // measured by the device kernel (header.scatter_max) and the fused kernels check that before using the section.
-  return (kind == AA_TABLE_PIL || kind == AA_TABLE_F32) ? 6 : 0;
+  return (kind == AA_TABLE_PIL || kind == AA_TABLE_F32 || kind == AA_TABLE_F64) ? 6 : 0;
 }
 
 size_t aa_table_build_bytes(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale) {
   const int k = aa_table_ksize(filter, kind, in_size, out_size, align_corners, scale);
   if (k < 0) return 0;
-  return aa_table_total_bytes(kind, out_size, k) + aa_table_scatter_bytes(in_size, scatter_ksize_for(filter, kind, in_size, out_size));
+  return aa_table_total_bytes(kind, out_size, k) + aa_table_scatter_bytes(kind, in_size, scatter_ksize_for(filter, kind, in_size, out_size));
 }
 
 int aa_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
@@ -147,7 +147,7 @@ int aa_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int 
   if (k < 0) return k;
   if (!table_dev) return AA_ERR_NULL;
   const int sk = scatter_ksize_for(filter, kind, in_size, out_size);
-  if (table_bytes < aa_table_total_bytes(kind, out_size, k) + aa_table_scatter_bytes(in_size, sk)) return AA_ERR_WORKSPACE;
+  if (table_bytes < aa_table_total_bytes(kind, out_size, k) + aa_table_scatter_bytes(kind, in_size, sk)) return AA_ERR_WORKSPACE;
   return aa_launch_table_build(filter, kind, in_size, out_size, align_corners,
                                scale_for(kind, in_size, out_size, align_corners, scale), k, sk, table_dev,
                                (hipStream_t)stream);

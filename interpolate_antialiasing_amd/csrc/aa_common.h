@@ -57,8 +57,10 @@ __host__ __device__ inline TableView<WT> make_table_view(const void *table, int 
 int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
                           int ksize, int scatter_ksize, void *table_dev, hipStream_t stream);
 // bytes of the scatter section appended to AA_TABLE_PIL tables (0 when scatter_ksize == 0)
-__host__ __device__ inline size_t aa_table_scatter_bytes(int64_t in_size, int scatter_ksize) {
-  return scatter_ksize > 0 ? 32 * ((size_t)in_size + 1) : 0;  // one 8-int record per input index + a sentinel
+__host__ __device__ inline size_t aa_table_scatter_pitch(int kind) { return kind == AA_TABLE_F64 ? 64 : 32; }
+__host__ __device__ inline size_t aa_table_scatter_bytes(int kind, int64_t in_size, int scatter_ksize) {
+  // one record per input index + a sentinel: 8 ints (32-bit weights), or {int32 first, int32 cc, double w[6], pad} = 64 bytes
+  return scatter_ksize > 0 ? aa_table_scatter_pitch(kind) * ((size_t)in_size + 1) : 0;
 }
 int aa_launch_table_transpose(const aa_table_header &h, const void *table_dev, void *tr_dev, int tr_ksize,
                               hipStream_t stream);

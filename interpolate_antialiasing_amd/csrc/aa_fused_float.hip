@@ -63,6 +63,15 @@ __device__ inline float select_by_mask(float a, float b, unsigned long long mask
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(mask));
   return d;
 }
+__device__ inline double select_by_mask(double a, double b, unsigned long long mask) {  // two halves
+  const unsigned long long ua = __double_as_longlong(a), ub = __double_as_longlong(b);
+  unsigned lo, hi;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)ua), "v"((unsigned)ub), "s"(mask));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((unsigned)(ua >> 32)), "v"((unsigned)(ub >> 32)), "s"(mask));
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+template <int DT> struct RealOf { typedef float type; };
+template <> struct RealOf<AA_F64> { typedef double type; };
 
 // element <-> float: 16-bit floats are storage types only: fp32 arithmetic, fp32 intermediate, ONE rounding to
 // nearest even at the store — exactly half(reference_fp32(float(x))), like the generic path's Store<> (aa_generic.hip)
@@ -98,7 +107,8 @@ template <int NQ, int G, int NDMA, int MAXC, int DT, int CS = 1>
 __global__ void __launch_bounds__(512)
 fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const char *__restrict__ tab_w,
                       const char *__restrict__ tab_h, const FusedF32Params p) {
-  constexpr int ES = DT == AA_F32 ? 4 : 2;  // element bytes
+  typedef typename RealOf<DT>::type real;  // arithmetic type: double for AA_F64 planes (AA_TABLE_F64 tables), else float
+  constexpr int ES = DT == AA_F64 ? 8 : (DT == AA_F32 ? 4 : 2);  // element bytes
   constexpr int EPQ = 16 / ES;              // elements per aligned 16-byte read
   constexpr int TWP = EPQ * NQ;
   constexpr int TW = CS == 1 ? TWP - (EPQ - 1) : TWP;  // taps a lane can hold
@@ -124,7 +134,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
 
   const int32_t *__restrict__ xmin_w = (const int32_t *)(tab_w + aa_table_xmin_off());
   const int32_t *__restrict__ xsize_w = (const int32_t *)(tab_w + aa_table_xsize_off(p.oWp));
-  const float *__restrict__ kw = (const float *)(tab_w + aa_table_w_off(p.oWp));
+  const real *__restrict__ kw = (const real *)(tab_w + aa_table_w_off(p.oWp));
   const int32_t *__restrict__ ymin_h = (const int32_t *)(tab_h + aa_table_xmin_off());
   const int32_t *__restrict__ ysize_h = (const int32_t *)(tab_h + aa_table_xsize_off(p.oH));
   const int32_t *__restrict__ sc_rec = (const int32_t *)(tab_h + p.sc_off);
@@ -150,13 +160,13 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   const int start = CS == 1 ? xm - lead : (xm - lead) * CS + (oe - ox * CS);  // row position (elements) of the first readable one
   const int astart = CS == 1 ? (start & ~(EPQ - 1)) : start;  // planes: rounded down to the 16-byte grid of the row image
   const int tap0 = CS == 1 ? (start & (EPQ - 1)) + lead : lead;  // window position of the reference's tap 0
-  float wreg[TWP];
+  real wreg[TWP];
   unsigned long long inwin[TWP];  // lane masks (scalar registers): position q belongs to the lane's own taps
 #pragma unroll
   for (int q = 0; q < TWP; q++) {
     const int j = q - tap0;
     const bool mine = j >= 0 && j < xs;
-    wreg[q] = (mine && j < p.ksize_w) ? kw[(size_t)ox * p.ksize_w + j] : 0.0f;
+    wreg[q] = (mine && j < p.ksize_w) ? kw[(size_t)ox * p.ksize_w + j] : (real)0;
     inwin[q] = __ballot(mine);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table loads done: from here on vmcnt counts DMAs and stores
@@ -189,9 +199,9 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   unsigned a = (unsigned)seg0 * (unsigned)ES + (unsigned)r_begin * row_bytes;
 
   // ---- vertical-pass state: MAXC accumulators, A[k] belongs to output row o_base + k -----------------------------
-  float A[MAXC];
+  real A[MAXC];
 #pragma unroll
-  for (int k2 = 0; k2 < MAXC; k2++) A[k2] = -0.0f;
+  for (int k2 = 0; k2 < MAXC; k2++) A[k2] = (real)-0.0;
   int o_base = oy0;
 
   auto dma = [&](unsigned a_row, int slot) {
@@ -202,25 +212,37 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst + 1024 * i), 16, voff + 1024u * i, a_row, 0, 0);
     }
   };
-  struct Scatter { int first; int cc; float w[MAXC]; };
-  auto load_scatter = [&](int r) -> Scatter {  // one 32-byte record: {first, count | completes << 16, w[6]}; r == H: sentinel
+  struct Scatter { int first; int cc; real w[MAXC]; };
+  auto load_scatter = [&](int r) -> Scatter {  // one record: {first, count | completes << 16, w[6]} (32 bytes; 64 with double weights); r == H: sentinel
     Scatter s;
-    const int32_t *rec = (const int32_t *)((const char *)sc_rec + (unsigned)r * 32u);
+    const int32_t *rec = (const int32_t *)((const char *)sc_rec + (unsigned)r * (DT == AA_F64 ? 64u : 32u));
     s.first = __builtin_amdgcn_readfirstlane(rec[0]);
     s.cc = __builtin_amdgcn_readfirstlane(rec[1]);
 #pragma unroll
-    for (int k2 = 0; k2 < MAXC; k2++) s.w[k2] = __int_as_float(__builtin_amdgcn_readfirstlane(rec[2 + k2]));
+    for (int k2 = 0; k2 < MAXC; k2++) {
+      if constexpr (DT == AA_F64) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(rec[2 + 2 * k2]), hi = (unsigned)__builtin_amdgcn_readfirstlane(rec[3 + 2 * k2]);
+        s.w[k2] = __longlong_as_double(((unsigned long long)hi << 32) | lo);
+      } else {
+        s.w[k2] = __int_as_float(__builtin_amdgcn_readfirstlane(rec[2 + k2]));
+      }
+    }
     return s;
   };
   auto emit = [&](int oy) {  // accumulator 0 is complete: store it, slide the others down
-    if constexpr (DT == AA_F32) {
+    if constexpr (DT == AA_F64) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const unsigned long long bits = __double_as_longlong(A[0]);
+      const u32x2 t = {(unsigned)bits, (unsigned)(bits >> 32)};
+      if (active) __builtin_amdgcn_raw_buffer_store_b64(t, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+    } else if constexpr (DT == AA_F32) {
       if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(A[0]), orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
     } else {
       if (active) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_elem<DT>(A[0]), orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
     }
 #pragma unroll
     for (int k2 = 0; k2 + 1 < MAXC; k2++) A[k2] = A[k2 + 1];
-    A[MAXC - 1] = -0.0f;
+    A[MAXC - 1] = (real)-0.0;
   };
   // one input row: window from LDS, reference-order accumulation over the lane's own taps, scatter into the open outputs
   auto row_step = [&](int slot, const Scatter &sc) {
@@ -236,15 +258,16 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
 #pragma unroll
       for (int q = 0; q < TWP; q++) dt[q] = st[q * CS];
     }
-    float acc = -0.0f;
+    real acc = (real)-0.0;
 #pragma unroll
     for (int q = 0; q < TWP; q++) {
-      float dq;  // window position q as a float
+      real dq;  // window position q as a real
       if constexpr (CS != 1) dq = dt[q];
+      else if constexpr (DT == AA_F64) dq = __longlong_as_double(((unsigned long long)d[q >> 1][2 * (q & 1) + 1] << 32) | d[q >> 1][2 * (q & 1)]);
       else if constexpr (DT == AA_F32) dq = __uint_as_float(d[q >> 2][q & 3]);
       else dq = elem_to_f32<DT>(d[q >> 3][(q >> 1) & 3] >> (16 * (q & 1)));
-      const float prod = dq * wreg[q];
-      const float sum = acc + prod;
+      const real prod = dq * wreg[q];
+      const real sum = acc + prod;
       acc = select_by_mask(acc, sum, inwin[q]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the window is in registers: the caller may refill the slot)
@@ -391,6 +414,12 @@ int launch_interleaved(int nq, int maxc, const FusedF32Params &p, const AAProble
 // floats (5 .. 25 taps); 16-bit floats: 2 or 3 quads of 8 (9 / 17 taps: more positions would not leave scalar registers
 // for their lane masks)
 int quads_for(int taps, int epq) {
+  if (epq == 2) {  // doubles: 2 per aligned read, taps <= 2 * NQ - 1
+    const int opts[] = {2, 4, 6, 8, 11};
+    for (int o : opts)
+      if (taps <= 2 * o - 1) return o;
+    return 0;
+  }
   if (epq == 4) {
     const int opts[] = {2, 3, 4, 5, 7};
     for (int o : opts)
@@ -405,7 +434,7 @@ int quads_for(int taps, int epq) {
 struct F32Geometry { int nq, nstrips, strip_w, nseg, cs; };
 
 bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw, F32Geometry *g) {
-  const int es = dtype == AA_F32 ? 4 : 2, epq = 16 / es;
+  const int es = dtype == AA_F64 ? 8 : (dtype == AA_F32 ? 4 : 2), epq = 16 / es;
   const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
   g->cs = (layout == AA_NHWC && C > 1) ? (int)C : 1;
   if (aw.span64p1 <= 0) return false;
@@ -440,22 +469,23 @@ bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw
 
 bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah,
                                     const aa_axis *aw) {
-  if (dtype != AA_F32 && dtype != AA_F16 && dtype != AA_BF16) return false;
+  if (dtype != AA_F32 && dtype != AA_F16 && dtype != AA_BF16 && dtype != AA_F64) return false;
   if (layout != AA_NCHW && layout != AA_NHWC) return false;
-  if (!ah || !aw || ah->kind != AA_TABLE_F32 || aw->kind != AA_TABLE_F32) return false;
+  const int want_kind = dtype == AA_F64 ? AA_TABLE_F64 : AA_TABLE_F32;
+  if (!ah || !aw || ah->kind != want_kind || aw->kind != want_kind) return false;
   if (ah->scatter_off <= 0 || ah->scatter_max <= 0 || ah->scatter_max > 6) return false;
   if (H < ah->out_size) return false;
   F32Geometry g;
   if (!f32_geometry(dtype, layout, C, W, *aw, &g)) return false;
-  if ((uint64_t)H * W * 4 * g.cs > 0xFFFFFFF0ull) return false;
-  if ((uint64_t)ah->out_size * aw->out_size * 4 * g.cs > 0xFFFFFFF0ull) return false;
+  if ((uint64_t)H * W * 8 * g.cs > 0xFFFFFFF0ull) return false;
+  if ((uint64_t)ah->out_size * aw->out_size * 8 * g.cs > 0xFFFFFFF0ull) return false;
   if (!aa_grid_fits(N * C * g.nstrips)) return false;
   return true;
 }
 
 int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
   if (!aa_fused_float_nchw_applicable(q.dtype, q.layout, q.N, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
-  const int es = q.dtype == AA_F32 ? 4 : 2;
+  const int es = q.dtype == AA_F64 ? 8 : (q.dtype == AA_F32 ? 4 : 2);
   if (((uintptr_t)q.out & (es - 1)) != 0 || ((uintptr_t)q.in & (es - 1)) != 0) return 0;
   F32Geometry g;
   f32_geometry(q.dtype, q.layout, q.C, q.W, q.aw, &g);
@@ -490,12 +520,21 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
       case 5: rc = launch_q<5, AA_F32>(mc, p, q); break;
       default: rc = launch_q<7, AA_F32>(mc, p, q); break;
     }
+  } else if (q.dtype == AA_F64) {
+    switch (g.nq) {
+      case 2: rc = launch_q<2, AA_F64>(mc, p, q); break;
+      case 4: rc = launch_q<4, AA_F64>(mc, p, q); break;
+      case 6: rc = launch_q<6, AA_F64>(mc, p, q); break;
+      case 8: rc = launch_q<8, AA_F64>(mc, p, q); break;
+      default: rc = launch_q<11, AA_F64>(mc, p, q); break;
+    }
   } else if (q.dtype == AA_F16) {
     rc = g.nq == 2 ? launch_q<2, AA_F16>(mc, p, q) : launch_q<3, AA_F16>(mc, p, q);
   } else {
     rc = g.nq == 2 ? launch_q<2, AA_BF16>(mc, p, q) : launch_q<3, AA_BF16>(mc, p, q);
   }
   if (rc == 1 && g.cs != 1) *variant = "fused_f32_nhwc";
+  else if (rc == 1 && q.dtype == AA_F64) *variant = "fused_f64_nchw";
   else if (rc == 1) *variant = q.dtype == AA_F32 ? "fused_f32_nchw" : (q.dtype == AA_F16 ? "fused_f16_nchw" : "fused_bf16_nchw");
   return rc;
 }

@@ -230,14 +230,16 @@ __global__ void table_transpose_kernel(const char *fwd, int32_t *tmin, int32_t *
 
 // Scatter section of AA_TABLE_PIL tables: one 32-byte record per INPUT index x, read by the fused kernels with a
 // single s_load_dwordx8: {first output fed, number of outputs fed, weight in output first+0 .. first+5}.
+template <typename WT>
 __global__ void table_scatter_kernel(const char *fwd, int32_t *rec_all, int32_t *scatter_max, int in_size, int out_size,
                                      int ksize) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x > in_size) return;  // record in_size is a sentinel (feeds nothing, completes nothing): readers may prefetch it
   const int32_t *xmin = (const int32_t *)(fwd + aa_table_xmin_off());
   const int32_t *xsize = (const int32_t *)(fwd + aa_table_xsize_off(out_size));
-  const int32_t *w = (const int32_t *)(fwd + aa_table_w_off(out_size));
-  int32_t *rec = rec_all + (size_t)x * 8;
+  const WT *w = (const WT *)(fwd + aa_table_w_off(out_size));  // (int32 and float weights travel bit for bit; doubles as doubles)
+  constexpr int REC_INTS = sizeof(WT) == 8 ? 16 : 8;
+  int32_t *rec = rec_all + (size_t)x * REC_INTS;
   auto first_ending_after = [&](int row) {  // first o whose last input row, xmin[o] + max(xsize[o],1) - 1, is >= row
     int lo = 0, hi = out_size;
     while (lo < hi) {
@@ -257,9 +259,10 @@ __global__ void table_scatter_kernel(const char *fwd, int32_t *rec_all, int32_t 
   const int cnt = (x < in_size && lo - first > 0) ? lo - first : 0;
   rec[0] = first;
   rec[1] = cnt | (completes << 16);
+  WT *rw = (WT *)(rec + 2);  // (8-byte aligned: records are 32 or 64 bytes)
   for (int k = 0; k < 6; k++) {
     const int o = first + k;
-    rec[2 + k] = (k < cnt) ? w[(size_t)o * ksize + (x - xmin[o])] : 0;
+    rw[k] = (k < cnt) ? w[(size_t)o * ksize + (x - xmin[o])] : (WT)0;
   }
   atomicMax(scatter_max, cnt > 1 ? cnt : 1);
 }
@@ -284,7 +287,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
   h.span64p1 = 0;
   h.span4p1 = 0;
   h.gather_off = kind == AA_TABLE_F32 ? (int32_t)aa_table_weights_end(kind, out_size, ksize) : 0;
-  if ((kind == AA_TABLE_PIL || kind == AA_TABLE_F32) && scatter_ksize > 0) {
+  if (scatter_ksize > 0) {
     h.scatter_off = (int32_t)aa_table_total_bytes(kind, out_size, ksize);
     h.scatter_ksize = scatter_ksize;
   }
@@ -297,13 +300,19 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
                        (float)scale, t);
     if (h.scatter_off) {  // float weights travel through the 32-bit record fields bit for bit
       const int b2 = (int)((in_size + 1 + threads - 1) / threads);
-      hipLaunchKernelGGL(table_scatter_kernel, dim3(b2), dim3(threads), 0, stream, (const char *)t,
+      hipLaunchKernelGGL(table_scatter_kernel<int32_t>, dim3(b2), dim3(threads), 0, stream, (const char *)t,
                          (int32_t *)(t + h.scatter_off), &((aa_table_header *)t)->scatter_max, (int)in_size, (int)out_size,
                          ksize);
     }
   } else if (kind == AA_TABLE_F64) {
     hipLaunchKernelGGL(table_build_f64, dim3(blocks), dim3(threads), 0, stream, filter, (int)in_size, (int)out_size, ksize,
                        scale, t);
+    if (h.scatter_off) {  // 64-byte records: double weights
+      const int b2 = (int)((in_size + 1 + threads - 1) / threads);
+      hipLaunchKernelGGL(table_scatter_kernel<double>, dim3(b2), dim3(threads), 0, stream, (const char *)t,
+                         (int32_t *)(t + h.scatter_off), &((aa_table_header *)t)->scatter_max, (int)in_size, (int)out_size,
+                         ksize);
+    }
   } else {
     hipLaunchKernelGGL(table_build_pil, dim3(blocks), dim3(threads), 0, stream, filter, (int)in_size, (int)out_size, ksize,
                        t);
@@ -311,7 +320,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
       // scatter (adjoint-form) section for the fused kernels' in-register vertical pass: for every INPUT index the
       // outputs it feeds and their fixed-point weights
       const int b2 = (int)((in_size + 1 + threads - 1) / threads);
-      hipLaunchKernelGGL(table_scatter_kernel, dim3(b2), dim3(threads), 0, stream, (const char *)t,
+      hipLaunchKernelGGL(table_scatter_kernel<int32_t>, dim3(b2), dim3(threads), 0, stream, (const char *)t,
                          (int32_t *)(t + h.scatter_off), &((aa_table_header *)t)->scatter_max, (int)in_size, (int)out_size,
                          ksize);
     }

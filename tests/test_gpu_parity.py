@@ -355,6 +355,8 @@ def test_fused_kernels_match_generic_at_full_size(aa):
     cases += [(aa.linear_forward, xfl, [196, 320]), (aa.cubic_forward, xfl, [196, 320]), (aa.nearest_forward, xfl[:2], [200, 300])]
     xf4 = (torch.rand(2, 4, 300, 500, device="cuda") - 0.3).contiguous(memory_format=torch.channels_last)
     cases += [(aa.linear_forward, xf4, [111, 204]), (aa.cubic_forward, xf4, [150, 251])]
+    xd = (torch.rand(2, 3, 438, 906, device="cuda", dtype=torch.float64) * 255)                          # fp64 (the reference dispatches double, s2.2:609-614)
+    cases += [(aa.linear_forward, xd, [196, 320]), (aa.cubic_forward, xd, [196, 320]), (aa.nearest_forward, xd, [200, 300])]
     xc = torch.rand(3, 3, 1024, 1024, device="cuda") * 255                                              # config 2 shape
     cases += [(aa.cubic_forward, xc, [224, 224]), (aa.linear_forward, xc, [224, 224])]
     xo = torch.rand(2, 2, 333, 517, device="cuda") - 0.5                                                # odd sizes, signed data
@@ -380,7 +382,7 @@ def test_fused_kernels_match_generic_at_full_size(aa):
     finally:
         _lib.set_fused(1)
     assert {"fused_u8_nhwc_pil_v3", "fused_u8_planar_pil_v3", "fused_u8_nhwc_harness_v3", "fused_u8_planar_harness_v3", "fused_f32_nchw",
-            "fused_f32_nchw_up", "fused_f32_nhwc"} <= fused_seen, fused_seen
+            "fused_f32_nchw_up", "fused_f32_nhwc", "fused_f64_nchw"} <= fused_seen, fused_seen
 
 
 def test_all_fused_generations_agree(aa):

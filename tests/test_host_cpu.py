@@ -50,7 +50,7 @@ def test_ksize_host_arithmetic_matches_oracle():
     assert L.aa_table_bytes(_lib.TABLE_F32, 320, 7) == 64 + ((8 * 320 + 15) // 16) * 16 + 320 * 7 * 4 + 32 * 320  # + gather records
     assert L.aa_table_build_bytes(0, _lib.TABLE_PIL, 438, 196, 0, 0.0) == L.aa_table_bytes(_lib.TABLE_PIL, 196, 7) + 32 * (438 + 1)
     assert L.aa_table_build_bytes(1, _lib.TABLE_F32, 1024, 224, 0, 0.0) == L.aa_table_bytes(_lib.TABLE_F32, 224, 21) + 32 * (1024 + 1)
-    assert L.aa_table_build_bytes(0, _lib.TABLE_F64, 438, 196, 0, 0.0) == L.aa_table_bytes(_lib.TABLE_F64, 196, 7)
+    assert L.aa_table_build_bytes(0, _lib.TABLE_F64, 438, 196, 0, 0.0) == L.aa_table_bytes(_lib.TABLE_F64, 196, 7) + 64 * (438 + 1)  # double-weight records
 
 
 def test_argument_errors_without_gpu():
