@@ -35,6 +35,9 @@
 #ifndef AA_UP_G
 #define AA_UP_G 8  // staged input rows per wave
 #endif
+#ifndef AA_UP_DMA_AUX
+#define AA_UP_DMA_AUX 0    // cache-policy bits of the staging DMA (developer knob; nt loads are slower: neighbouring strips and bands re-read rows)
+#endif
 #ifndef AA_UP_ABL
 #define AA_UP_ABL 0  // developer ablations (wrong results): 1 no output stores, 2 no input (no DMA, no horizontal pass), 3 stores
                      // of every output row land on row 0 (stay in cache)
@@ -49,6 +52,10 @@ struct FusedF32UpParams {
   int ksize_w, ksize_h;
   int ybands, nstrips, strips_per_block, strip_w;
   int nseg, seg_bytes;
+  int store_nt;    // output far larger than the caches: wide stores with the streaming (nt) policy.  This path writes 6x what it
+                   // reads; with the default policy the written lines push the input rows (re-read by neighbouring strips and
+                   // bands) out of L2 / the Infinity Cache and reads queue behind writes: measured -33 % (row pitch a multiple of
+                   // 64 B) to -8 % (oW = 906) with nt (profiles/r02_headline_experiments.txt)
   int gather_off;  // gather section of the H table: one 32-byte record {ymin, ysize, w[6]} per output row
   unsigned long long plane_in_bytes, plane_out_bytes, total_in_bytes, total_out_bytes;
   long long n_groups;  // (plane, band) groups = planes * ybands
@@ -178,7 +185,7 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   auto dma = [&](int row, int slot) {
     const int dst = lds_base + slot * p.seg_bytes;
     if (dma_lane)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, a_base + (unsigned)row * row_bytes, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, a_base + (unsigned)row * row_bytes, 0, AA_UP_DMA_AUX);
     vm_issued++;
     idxv = (lane == slot) ? vm_issued : idxv;
   };
@@ -281,7 +288,10 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const u32x4 t = {__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
       if (bw >= CPL) {
-        if (full_lane && (AA_UP_ABL != 1 || t.x == 0x12345678u)) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 0);
+        if (full_lane && (AA_UP_ABL != 1 || t.x == 0x12345678u)) {
+          if (p.store_nt) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 2);
+          else __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 0);
+        }
         if (AA_UP_ABL != 1) vm_issued++;
       }
     } else if constexpr (CPL == 2) {
@@ -437,6 +447,7 @@ int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   p.nseg = g.nseg;
   p.seg_bytes = p.nseg * 16;
   p.gather_off = q.ah.gather_off;
+  p.store_nt = (p.total_out_bytes > (64ull << 20) && !getenv("AA_UP_NO_NT")) ? 1 : 0;
   p.ybands = 1;
   p.n_groups = 0;
   const size_t lds = (size_t)AA_UP_G * p.seg_bytes;
