@@ -41,6 +41,8 @@ struct FusedF32Params {
   int ybands, nstrips, strips_per_block, strip_w;
   int nseg, seg_bytes;
   int sc_off;
+  int store_nt;  // outputs far larger than the caches are stored with the streaming (nt) policy: -3 .. -8 % (they are written once and
+                 // never read here; with the default policy they displace input rows that neighbouring strips and bands re-read)
   unsigned long long plane_in_bytes, plane_out_bytes, total_in_bytes, total_out_bytes;
   long long n_groups;  // (plane, band) groups = planes * ybands
 };
@@ -234,9 +236,15 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       const unsigned long long bits = __double_as_longlong(A[0]);
       const u32x2 t = {(unsigned)bits, (unsigned)(bits >> 32)};
-      if (active) __builtin_amdgcn_raw_buffer_store_b64(t, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+      if (active) {
+        if (p.store_nt) __builtin_amdgcn_raw_buffer_store_b64(t, orsrc, store_voff, (unsigned)oy * out_row_bytes, 2);
+        else __builtin_amdgcn_raw_buffer_store_b64(t, orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+      }
     } else if constexpr (DT == AA_F32) {
-      if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(A[0]), orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+      if (active) {
+        if (p.store_nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(A[0]), orsrc, store_voff, (unsigned)oy * out_row_bytes, 2);
+        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(A[0]), orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
+      }
     } else {
       if (active) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_elem<DT>(A[0]), orsrc, store_voff, (unsigned)oy * out_row_bytes, 0);
     }
@@ -500,6 +508,7 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
   p.total_in_bytes = p.plane_in_bytes * planes;
   p.total_out_bytes = p.plane_out_bytes * planes;
   p.sc_off = q.ah.scatter_off;
+  p.store_nt = p.total_out_bytes > (64ull << 20) ? 1 : 0;
   p.nstrips = g.nstrips;
   p.strip_w = g.strip_w;
   p.strips_per_block = p.nstrips <= 8 ? p.nstrips : 4;
