@@ -54,6 +54,10 @@
                        // instruction - where it blocks, in order, while the CU's address FIFO is full - every BURST rows
 #endif
 
+#ifndef AA_V3_F32OUT_AUX
+#define AA_V3_F32OUT_AUX 0  // cache policy of the float32-output stores (decode-adjacent conversion).  nt measured: NCHW output 0.478 -> 0.505 ms, NHWC unchanged: default kept
+#endif
+
 #ifndef AA_V3_UNALIGNED
 #define AA_V3_UNALIGNED 0  // 1: window reads straight from the window's BYTE address (gfx950's LDS does serve unaligned
                            // ds_read_b32/b64, and hipcc emits them for align-1 pointers), saving the 5 v_alignbyte per row.
@@ -334,19 +338,19 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           for (int c = 0; c < C; c++)
             if (active)
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[c]), orsrc, (unsigned)(ox0 + lane_o) * 4u,
-                                                    ((unsigned)c * (unsigned)p.oH + (unsigned)oy) * (unsigned)p.oW * 4u, 0);
+                                                    ((unsigned)c * (unsigned)p.oH + (unsigned)oy) * (unsigned)p.oW * 4u, AA_V3_F32OUT_AUX);
         } else {
           const unsigned fv = (unsigned)(ox0 + lane_o) * (unsigned)(4 * C), fs = (unsigned)oy * (unsigned)p.oW * (unsigned)(4 * C);
           if constexpr (C == 3) {
             typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
             const u32x3 t = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
-            if (active) __builtin_amdgcn_raw_buffer_store_b96(t, orsrc, fv, fs, 0);
+            if (active) __builtin_amdgcn_raw_buffer_store_b96(t, orsrc, fv, fs, AA_V3_F32OUT_AUX);
           } else if constexpr (C == 4) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 t = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-            if (active) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, fv, fs, 0);
+            if (active) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, fv, fs, AA_V3_F32OUT_AUX);
           } else {
-            if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), orsrc, fv, fs, 0);
+            if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), orsrc, fv, fs, AA_V3_F32OUT_AUX);
           }
         }
         stored = true;
