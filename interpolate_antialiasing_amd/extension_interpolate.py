@@ -267,6 +267,32 @@ def _backward(filter_id: int, name: str, grad_output: torch.Tensor, output_size:
     return gi
 
 
+def _axis_pass_2d(L, x, y, dt, kind, outer, n_in, n_out, inner, table, dev, stream) -> bool:
+    """One separable pass of an N-d resample through the FUSED 2-D kernels: the dense array [outer][n][inner] is a stack of 2-D
+    images in which only one axis changes — [1,1,outer,n] -> [1,1,outer,n_out] when inner == 1 (the pass runs along rows),
+    [outer,1,n,inner] -> [outer,1,n_out,inner] otherwise (along columns) — and the other axis gets the IDENTITY table (box filter,
+    same size: one tap of weight exactly 1.0, so x * 1.0 = x bit for bit and no neighbour is ever touched).  Same bytes moved as
+    the generic single-axis kernel, but through the streaming kernels.  Returns False (caller runs the generic axis kernel) for
+    sizes the 2-D entry point cannot index."""
+    if inner == 1:
+        n2, h2, w2, oh2, ow2 = 1, outer, n_in, outer, n_out
+        th = tables.get_table(_lib.FILTER_BOX, kind, outer, outer, False, 0.0, dev)
+        tw = table
+    else:
+        n2, h2, w2, oh2, ow2 = outer, n_in, inner, n_out, inner
+        th = table
+        tw = tables.get_table(_lib.FILTER_BOX, kind, inner, inner, False, 0.0, dev)
+    if max(h2, w2, oh2, ow2) >= (1 << 24):
+        return False
+    ah, aw = th.axis(), tw.axis()
+    ws_bytes = L.aa_workspace_bytes(dt, _lib.NCHW, n2, 1, h2, w2, oh2, ow2, ctypes.byref(ah), ctypes.byref(aw))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    rc = L.aa_resample_fwd(x.data_ptr(), y.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, dt, _lib.NCHW,
+                           n2, 1, h2, w2, ctypes.byref(ah), ctypes.byref(aw), stream)
+    _lib.check(rc, "aa_resample_fwd (axis pass)")
+    return True
+
+
 def _forward_nd(filter_id: int, name: str, input: torch.Tensor, output_size: Sequence[int], align_corners: bool) -> torch.Tensor:
     """1-D (NCL) and 3-D (NCDHW) front-ends: the reference's separable driver is N-d generic
     (s2.2/aa_interpolation_impl.h:536-683, "NCHW, NCL or NCKHW" :545) although only the 2-D callables are bound.
@@ -308,12 +334,13 @@ def _forward_nd(filter_id: int, name: str, input: torch.Tensor, output_size: Seq
             for v in shape[3 + k:]:
                 inner *= v
             t = tables.get_table(filter_id, kind, n_in, n_out, align_corners, 0.0, dev)
-            ax = t.axis()
             shape[2 + k] = n_out
             y = torch.empty(shape, dtype=x.dtype, device=dev)
-            rc = L.aa_resample_axis_fwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), dt, outer, n_in, inner,
-                                        ctypes.byref(ax), s)
-            _lib.check(rc, name)
+            if not _axis_pass_2d(L, x, y, dt, kind, outer, n_in, n_out, inner, t, dev, s):
+                ax = t.axis()
+                rc = L.aa_resample_axis_fwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), dt, outer, n_in, inner,
+                                            ctypes.byref(ax), s)
+                _lib.check(rc, name)
             x = y
     return x
 
@@ -356,12 +383,14 @@ def _backward_nd(filter_id: int, name: str, grad_output: torch.Tensor, output_si
             for v in shape[3 + k:]:
                 inner *= v
             fwd = tables.get_table(filter_id, kind, n_in_fwd, n_out_fwd, align_corners, 0.0, dev)
-            ax = tables.get_transposed_table(fwd).axis()  # maps n_out_fwd -> n_in_fwd
+            tr = tables.get_transposed_table(fwd)  # maps n_out_fwd -> n_in_fwd
             shape[2 + k] = n_in_fwd
             y = torch.empty(shape, dtype=g.dtype, device=dev)
-            rc = L.aa_resample_axis_fwd(ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(y.data_ptr()), dt, outer, n_out_fwd, inner,
-                                        ctypes.byref(ax), s)
-            _lib.check(rc, name)
+            if not _axis_pass_2d(L, g, y, dt, kind, outer, n_out_fwd, n_in_fwd, inner, tr, dev, s):
+                ax = tr.axis()
+                rc = L.aa_resample_axis_fwd(ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(y.data_ptr()), dt, outer, n_out_fwd, inner,
+                                            ctypes.byref(ax), s)
+                _lib.check(rc, name)
             g = y
     return g
 

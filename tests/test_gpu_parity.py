@@ -502,6 +502,39 @@ def test_1d_and_3d_front_ends(aa, dt):
     assert np.array_equal(interpolate_aa(_gpu(x3), (7, 9, 11), "trilinear").cpu().numpy(), aa.linear_forward_nd(_gpu(x3), [7, 9, 11]).cpu().numpy())
 
 
+def test_nd_passes_take_the_fused_kernels(aa):
+    """The 1-D / 3-D front-ends run every axis pass through the fused 2-D kernels (identity table on the other axis): at sizes
+    where that matters the results stay bit-identical to the generic single-axis kernel and to the oracle applied axis by axis."""
+    from interpolate_antialiasing_amd import _lib
+
+    torch.manual_seed(41)
+    x1 = torch.rand(4, 3, 4000, device="cuda") * 255 - 30
+    x3 = torch.rand(2, 2, 40, 120, 300, device="cuda") * 255
+    for fn, x, size in ((aa.linear_forward_nd, x1, [1300]), (aa.cubic_forward_nd, x1, [900]), (aa.linear_forward_nd, x1, [6000]),
+                        (aa.linear_forward_nd, x3, [17, 50, 110]), (aa.cubic_forward_nd, x3, [40, 61, 300]), (aa.linear_forward_nd, x3, [60, 120, 100])):
+        try:
+            _lib.set_fused(1)
+            y1 = fn(x, size)
+            v = _lib.last_variant()
+            _lib.set_fused(0)
+            y0 = fn(x, size)
+        finally:
+            _lib.set_fused(1)
+        assert v.startswith("fused"), (v, tuple(x.shape), size)
+        assert torch.equal(y1, y0), (tuple(x.shape), size)
+    exp = _oracle_axis("linear", x1[:1].cpu().numpy(), 2, 1300)
+    assert np.array_equal(aa.linear_forward_nd(x1[:1], [1300]).cpu().numpy(), exp)
+    g = torch.randn(4, 3, 1300, device="cuda", dtype=torch.float64)
+    try:
+        _lib.set_fused(1)
+        b1 = aa.linear_backward_nd(g, [1300], [4, 3, 4000])
+        _lib.set_fused(0)
+        b0 = aa.linear_backward_nd(g, [1300], [4, 3, 4000])
+    finally:
+        _lib.set_fused(1)
+    assert torch.equal(b1, b0)
+
+
 def test_nd_matches_torch_upstream(aa):
     """Independent cross-check (never the implementation): PyTorch's own antialiased interpolate is 2-D only, so compare
     the 1-D front-end with F.interpolate on an [N,C,1,L] view (its H pass is an exact identity)."""
