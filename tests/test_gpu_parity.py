@@ -904,3 +904,35 @@ def test_fuzz_fused_equals_generic(aa):
             raise AssertionError((it, str(dt), c, (n, h, w), (oh, ow), cl, filt, kind, v, d))
         assert same, (it, str(dt), c, (n, h, w), (oh, ow), cl, filt, kind, v)
     assert fused >= 45, fused  # about half of the random problems take a fused kernel (the rest: C = 2 or 5, fp64 channels_last, ...)
+
+
+def test_fuzz_vs_oracle_small(aa):
+    """80 seeded random small problems straight against the oracle (bit-exact): fp32 / fp64 forward in both layouts, uint8 in Pillow
+    and harness arithmetic, including sizes of 1, up-scales and windows clipped at both borders."""
+    rng = np.random.default_rng(77)
+    for it in range(80):
+        c = int(rng.choice([1, 3, 4]))
+        n = int(rng.integers(1, 3))
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        oh = int(rng.integers(1, 120))
+        ow = int(rng.integers(1, 120))
+        filt = FILTS[int(rng.integers(3))]
+        cl = bool(rng.integers(2))
+        kind = int(rng.integers(4))
+        if kind == 0:
+            x = (rng.random((n, c, h, w)) * 300 - 40).astype(np.float32)
+            exp = oracle.forward(filt, x, (oh, ow))
+            got = _fn(aa, filt)(_gpu(x, cl), [oh, ow]).cpu().numpy()
+        elif kind == 1:
+            x = (rng.random((n, c, h, w)) * 300 - 40).astype(np.float64)
+            exp = oracle.forward(filt, x, (oh, ow))
+            got = _fn(aa, filt)(_gpu(x, cl), [oh, ow]).cpu().numpy()
+        elif kind == 2:
+            x = rng.integers(0, 256, (n, c, h, w), dtype=np.uint8)
+            exp = oracle.pil_resize_u8(filt, x, (oh, ow))
+            got = _fn(aa, filt)(_gpu(x, cl), [oh, ow]).cpu().numpy()
+        else:
+            x = rng.integers(0, 256, (n, c, h, w), dtype=np.uint8)
+            exp = oracle.harness_u8(filt, x, (oh, ow))
+            got = _fn(aa, filt)(_gpu(x, cl), [oh, ow], uint8_mode="harness").cpu().numpy()
+        assert np.array_equal(got, exp), (it, kind, filt, (n, c, h, w), (oh, ow), cl)
