@@ -55,7 +55,8 @@ struct FusedF32UpParams {
   int store_nt;    // output far larger than the caches: wide stores with the streaming (nt) policy.  This path writes 6x what it
                    // reads; with the default policy the written lines push the input rows (re-read by neighbouring strips and
                    // bands) out of L2 / the Infinity Cache and reads queue behind writes: measured -33 % (row pitch a multiple of
-                   // 64 B) to -8 % (oW = 906) with nt (profiles/r02_headline_experiments.txt)
+                   // 64 B) to -8 % (oW = 906) with nt (profiles/r02_headline_experiments.txt).  2 = rows that are not whole
+                   // 64-byte sectors: nt for the whole sectors of a piece only (see the store), a further -5..-25 % for oW = 906
   int gather_off;  // gather section of the H table: one 32-byte record {ymin, ysize, w[6]} per output row
   unsigned long long plane_in_bytes, plane_out_bytes, total_in_bytes, total_out_bytes;
   long long n_groups;  // (plane, band) groups = planes * ybands
@@ -176,6 +177,7 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   const unsigned out_row_bytes = (unsigned)p.oW * 4u;
   const unsigned store_voff = (unsigned)(ox0 + col0) * 4u;
   const bool full_lane = col0 + CPL <= bw;  // all CPL columns of the lane exist: one wide store
+  const unsigned phase0 = (unsigned)(((unsigned long long)(uintptr_t)out + out_off + (unsigned long long)ox0 * 4u) & 127u);
 
   const unsigned a_base = (unsigned)seg0 * 4u;  // byte offset (from the plane) of the strip's segment in row 0
 
@@ -287,9 +289,31 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
     if constexpr (CPL == 4) {
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const u32x4 t = {__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
-      if (bw >= CPL) {
+      if (p.store_nt == 2 && bw >= CPL) {
+        // Output rows that are not whole 64-byte sectors (oW = 906: 3624 B): the sectors a piece shares with its
+        // neighbouring strip are written half by each, and a streamed (nt) half-sector write costs a read-modify-write
+        // at the memory.  So only the lanes whose 16 bytes lie in whole sectors of the piece stream; the lanes of its
+        // two end sectors store with the default policy and the L2 merges the halves.  Measured on [256,3,438,906]
+        // gradients: 0.395-0.44 ms (all nt) -> 0.32-0.376 ms depending on the box / buffer placement; aligned widths
+        // keep the single store (the split costs them 3 %).
+        const unsigned P = (phase0 + soff) & 63u;
+        const unsigned nl_full = (unsigned)bw / CPL;
+        const unsigned E = P + 16u * nl_full;
+        const unsigned IA = (P + 63u) & ~63u, IB = E & ~63u;
+        const unsigned lo = (IA - P + 15u) >> 4;
+        const unsigned hi = IB > IA ? (IB - P) >> 4 : lo;
+        const bool interior = (unsigned)lane >= lo && (unsigned)lane < hi;
+        if (hi > lo) {  // (lane lo is a full, interior lane: the store is issued)
+          if (full_lane && interior) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 2);
+          vm_issued++;
+        }
+        if (lo > 0 || hi < nl_full) {  // (lane 0 or lane hi is a full end lane)
+          if (full_lane && !interior) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 0);
+          vm_issued++;
+        }
+      } else if (bw >= CPL) {
         if (full_lane && (AA_UP_ABL != 1 || t.x == 0x12345678u)) {
-          if (p.store_nt) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 2);
+          if (p.store_nt != 0) __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 2);
           else __builtin_amdgcn_raw_buffer_store_b128(t, orsrc, store_voff, soff, 0);
         }
         if (AA_UP_ABL != 1) vm_issued++;
@@ -448,6 +472,9 @@ int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   p.seg_bytes = p.nseg * 16;
   p.gather_off = q.ah.gather_off;
   p.store_nt = (p.total_out_bytes > (64ull << 20) && !getenv("AA_UP_NO_NT")) ? 1 : 0;
+  // rows or planes that are not whole 64-byte sectors: stream only the whole sectors of each piece (see the store)
+  if (p.store_nt && g.cpl == 4 && ((((uintptr_t)q.out) | (uint64_t)q.oW * 4u | p.plane_out_bytes) & 63u) != 0 && !getenv("AA_UP_NO_SPLIT"))
+    p.store_nt = 2;
   p.ybands = 1;
   p.n_groups = 0;
   const size_t lds = (size_t)AA_UP_G * p.seg_bytes;

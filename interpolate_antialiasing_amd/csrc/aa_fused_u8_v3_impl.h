@@ -95,7 +95,10 @@ typedef __attribute__((address_space(3))) void lds_void;
 // cache policy of the output stores of the interleaved-channel kernels: nt (streaming).  Their 192-byte pieces are whole
 // 64-byte sectors, written once and never read here: -2 % against the default policy (sc0 alone changes nothing).  The
 // planar kernel's 64-byte pieces and the fp32 kernels' 244-byte pieces get SLOWER with nt (0.55 -> 0.59 / 0.62 ms): default.
-constexpr int kStoreAuxInterleaved = 2;
+#ifndef AA_V3_STORE_AUX
+#define AA_V3_STORE_AUX 2
+#endif
+constexpr int kStoreAuxInterleaved = AA_V3_STORE_AUX;
 
 
 

@@ -1,5 +1,5 @@
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from interpolate_antialiasing_amd import _lib, extension_interpolate as aa
 def timed(fn, reps=30):
     for _ in range(10): fn()

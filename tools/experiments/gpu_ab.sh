@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/gpu_ab.sh OUTDIR name1 name2 ...   (A/B of libaa_interp_<name>.so builds on the headline bench, 2 rounds)
+# usage: tools/experiments/gpu_ab.sh OUTDIR name1 name2 ...   (A/B of libaa_interp_<name>.so builds on the headline bench, 2 rounds)
 set -o pipefail
 OUT=gpurun_out/$1; shift
 mkdir -p $OUT

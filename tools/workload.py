@@ -50,4 +50,13 @@ else:
 for _ in range(launches):
     y = fn()
 torch.cuda.synchronize()
-print(name, _lib.last_variant(), tuple(y.shape))
+if os.environ.get("AA_TIME"):  # event-timed average over the same launches (A/B experiments)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        y = fn()
+    e1.record()
+    e1.synchronize()
+    print(f"{name} {e0.elapsed_time(e1) / launches:.4f} ms", _lib.last_variant(), flush=True)
+else:
+    print(name, _lib.last_variant(), tuple(y.shape))
