@@ -30,16 +30,19 @@ __device__ inline float to_f32(bf16_t x) { return __uint_as_float((unsigned)x.v 
 
 struct PipeF32 {
   using W = float; using Acc = float;
+  static __device__ inline Acc init() { return -0.0f; }  // (-0) + p == p exactly, for every p: the first tap is an assignment
   template <typename T> static __device__ inline Acc first(T x, W w) { return to_f32(x) * w; }
   template <typename T> static __device__ inline Acc next(Acc a, T x, W w) { return a + to_f32(x) * w; }
 };
 struct PipeF64 {
   using W = double; using Acc = double;
+  static __device__ inline Acc init() { return -0.0; }
   template <typename T> static __device__ inline Acc first(T x, W w) { return (double)x * w; }
   template <typename T> static __device__ inline Acc next(Acc a, T x, W w) { return a + (double)x * w; }
 };
 struct PipePIL {  // Pillow 8bpc: ss0 = 1 << (PRECISION_BITS-1); ss0 += pixel * k[x]
   using W = int32_t; using Acc = int32_t;
+  static __device__ inline Acc init() { return 1 << 21; }
   template <typename T> static __device__ inline Acc first(T x, W w) { return (1 << 21) + (int32_t)x * w; }
   template <typename T> static __device__ inline Acc next(Acc a, T x, W w) { return a + (int32_t)x * w; }
 };
@@ -74,51 +77,232 @@ template <> struct Store<uint8_t, float> {  // harness: (bicubic clamp, test.py:
 };
 
 // out[row][ox][ci] = sum_j in[row][xmin[ox]+j][ci] * w[ox][j]
-template <typename Pipe, typename TIn, typename TOut>
+// One thread owns one output column (ox, ci) and walks the rows R at a time: the column's window start, length and weights are
+// read once per R rows, and the R rows' taps are R independent loads per weight (the dependent chain is only the sum, in tap
+// order).  No per-element 64-bit divisions: the column index is a 32-bit quantity, the row index comes from the grid.
+template <typename Pipe, typename TIn, typename TOut, int R>
 __global__ void __launch_bounds__(256)
-hpass_generic(const TIn *__restrict__ in, TOut *__restrict__ out, const char *__restrict__ table, int64_t total,
+hpass_generic(const TIn *__restrict__ in, TOut *__restrict__ out, const char *__restrict__ table, int64_t rows,
               int W, int oW, int inner, int ksize) {
   using WT = typename Pipe::W;
+  using Acc = typename Pipe::Acc;
   const TableView<WT> tv = make_table_view<WT>(table, oW, ksize);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    const int ci = (int)(idx % inner);
-    const int64_t t = idx / inner;
-    const int ox = (int)(t % oW);
-    const int64_t row = t / oW;
-    const int xmin = tv.xmin[ox];
-    int n = tv.xsize[ox];
-    n = n > 1 ? n : 1;
-    const WT *w = tv.w + (size_t)ox * ksize;
-    const TIn *src = in + (row * W + xmin) * inner + ci;
-    typename Pipe::Acc acc = Pipe::first(src[0], w[0]);
-    for (int j = 1; j < n; j++) acc = Pipe::next(acc, src[(int64_t)j * inner], w[j]);
-    out[idx] = Store<TOut, typename Pipe::Acc>::cvt(acc, 0);
+  const int ncol = oW * inner;
+  int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const bool active = col < ncol;
+  col = active ? col : 0;
+  const int ox = col / inner;
+  const int ci = col - ox * inner;
+  const int xmin = tv.xmin[ox];
+  int n = tv.xsize[ox];
+  n = n > 1 ? n : 1;
+  const WT *__restrict__ w = tv.w + (size_t)ox * ksize;
+  const int64_t row_elems = (int64_t)W * inner;
+  const TIn *__restrict__ col_src = in + (int64_t)xmin * inner + ci;
+  for (int64_t row0 = (int64_t)blockIdx.y * R; row0 < rows; row0 += (int64_t)gridDim.y * R) {
+    const TIn *src[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int64_t row = row0 + r < rows ? row0 + r : rows - 1;  // (rows past the end re-read the last one; never stored)
+      src[r] = col_src + row * row_elems;
+    }
+    Acc acc[R];
+    const WT w0 = w[0];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = Pipe::first(src[r][0], w0);
+    for (int j = 1; j < n; j++) {
+      const WT wj = w[j];
+      const int64_t off = (int64_t)j * inner;
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] = Pipe::next(acc[r], src[r][off], wj);
+    }
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (row0 + r < rows) out[(row0 + r) * ncol + col] = Store<TOut, Acc>::cvt(acc[r], 0);
+    }
   }
 }
 
-// out[p][oy][e] = sum_j mid[p][ymin[oy]+j][e] * w[oy][j]
-template <typename Pipe, typename TIn, typename TOut>
+// Wide windows (strong down-scaling: 17 .. 40 taps): the same sum, but a thread owns one output PIXEL (all INNER channels) and
+// reads its window — xsize * INNER consecutive input elements — four elements per load instead of one per tap and channel.
+// Only whole groups of four taps are read that way (they lie inside the window, so inside the row); the last xsize % 4 taps
+// are read one by one.  Tap order and rounding are those of hpass_generic.
+template <typename T>
+struct alignas(sizeof(T)) Packed4 { T v[4]; };  // (element-aligned only: a window starts anywhere in the row)
+template <typename T>
+__device__ inline Packed4<T> load_packed4(const T *p) {
+  Packed4<T> r;
+  __builtin_memcpy(&r, p, sizeof(r));  // one 4/8/16/32-byte global load; the hardware accepts element alignment
+  return r;
+}
+
+template <typename Pipe, typename TIn, typename TOut, int INNER, int R>
 __global__ void __launch_bounds__(256)
-vpass_generic(const TIn *__restrict__ mid, TOut *__restrict__ out, const char *__restrict__ table, int64_t total,
+hpass_wide(const TIn *__restrict__ in, TOut *__restrict__ out, const char *__restrict__ table, int64_t rows, int W, int oW, int ksize) {
+  using WT = typename Pipe::W;
+  using Acc = typename Pipe::Acc;
+  const TableView<WT> tv = make_table_view<WT>(table, oW, ksize);
+  int ox = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const bool active = ox < oW;
+  ox = active ? ox : 0;
+  const int xmin = tv.xmin[ox];
+  int n = tv.xsize[ox];
+  n = n > 1 ? n : 1;
+  const WT *__restrict__ w = tv.w + (size_t)ox * ksize;
+  const int64_t row_elems = (int64_t)W * INNER;
+  const TIn *__restrict__ col_src = in + (int64_t)xmin * INNER;
+  const int nfull = n & ~3;  // taps covered by whole groups of four
+  for (int64_t row0 = (int64_t)blockIdx.y * R; row0 < rows; row0 += (int64_t)gridDim.y * R) {
+    const TIn *src[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+      src[r] = col_src + row * row_elems;
+    }
+    Acc acc[R][INNER];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int c = 0; c < INNER; c++) acc[r][c] = Pipe::init();
+    int j = 0;
+    {
+      for (; j < nfull; j += 4) {
+        WT wj[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) wj[k] = w[j + k];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          TIn x[4 * INNER];  // 4 taps x INNER channels, consecutive in memory
+#pragma unroll
+          for (int q = 0; q < INNER; q++) {
+            const Packed4<TIn> v = load_packed4(src[r] + (int64_t)j * INNER + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; k++) x[4 * q + k] = v.v[k];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < INNER; c++) acc[r][c] = Pipe::next(acc[r][c], x[k * INNER + c], wj[k]);
+        }
+      }
+    }
+    for (; j < n; j++) {
+      const WT wj = w[j];
+#pragma unroll
+      for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int c = 0; c < INNER; c++) {
+          acc[r][c] = Pipe::next(acc[r][c], src[r][(int64_t)j * INNER + c], wj);
+        }
+    }
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (row0 + r < rows) {
+#pragma unroll
+          for (int c = 0; c < INNER; c++) out[((row0 + r) * oW + ox) * INNER + c] = Store<TOut, Acc>::cvt(acc[r][c], 0);
+        }
+    }
+  }
+}
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) VecOf { T v[V]; };
+
+// out[p][oy][e] = sum_j mid[p][ymin[oy]+j][e] * w[oy][j]
+// A workgroup is 4 waves; each wave owns one output row (p, oy) at a time and 64 * VEC consecutive elements of it, so the row's
+// window start, length and weights are wave-uniform (scalar loads, a uniform tap loop) and every tap is one fully coalesced load
+// of 64 * VEC elements.
+template <typename Pipe, typename TIn, typename TOut, int VEC>
+__global__ void __launch_bounds__(256)
+vpass_generic(const TIn *__restrict__ mid, TOut *__restrict__ out, const char *__restrict__ table, int64_t planes,
               int H, int oH, int64_t rowlen, int ksize) {
   using WT = typename Pipe::W;
+  using Acc = typename Pipe::Acc;
   const TableView<WT> tv = make_table_view<WT>(table, oH, ksize);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    const int64_t e = idx % rowlen;
-    const int64_t t = idx / rowlen;
+  const int64_t e0 = ((int64_t)blockIdx.x * 64 + threadIdx.x) * VEC;
+  const bool active = e0 < rowlen;  // (rowlen is a multiple of VEC: a lane's VEC elements exist together)
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);  // blockDim.x == 64: a wave has one threadIdx.y
+  const int64_t total_rows = planes * oH;
+  for (int64_t t = (int64_t)blockIdx.y * 4 + wv; t < total_rows; t += (int64_t)gridDim.y * 4) {
     const int oy = (int)(t % oH);
     const int64_t p = t / oH;
     const int ymin = tv.xmin[oy];
     int n = tv.xsize[oy];
     n = n > 1 ? n : 1;
-    const WT *w = tv.w + (size_t)oy * ksize;
-    const TIn *src = mid + (p * H + ymin) * rowlen + e;
-    typename Pipe::Acc acc = Pipe::first(src[0], w[0]);
-    for (int j = 1; j < n; j++) acc = Pipe::next(acc, src[(int64_t)j * rowlen], w[j]);
-    out[idx] = Store<TOut, typename Pipe::Acc>::cvt(acc, 0);
+    const WT *__restrict__ w = tv.w + (size_t)oy * ksize;
+    const TIn *__restrict__ src = mid + (p * H + ymin) * rowlen + (active ? e0 : 0);
+    Acc acc[VEC];
+    {
+      const VecOf<TIn, VEC> x = *(const VecOf<TIn, VEC> *)src;
+      const WT w0 = w[0];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) acc[v] = Pipe::first(x.v[v], w0);
+    }
+#pragma unroll 4
+    for (int j = 1; j < n; j++) {
+      const VecOf<TIn, VEC> x = *(const VecOf<TIn, VEC> *)(src + (int64_t)j * rowlen);
+      const WT wj = w[j];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) acc[v] = Pipe::next(acc[v], x.v[v], wj);
+    }
+    if (active) {
+      VecOf<TOut, VEC> y;
+#pragma unroll
+      for (int v = 0; v < VEC; v++) y.v[v] = Store<TOut, Acc>::cvt(acc[v], 0);
+      *(VecOf<TOut, VEC> *)(out + t * rowlen + e0) = y;
+    }
   }
+}
+
+// rows of a pass spread over grid.y, at most 65535 workgroups there and about 32 workgroups per CU in all
+inline unsigned grid_y_for(int64_t units, unsigned grid_x) {
+  int64_t cap = (256 * 32 + grid_x - 1) / grid_x;
+  if (cap > 65535) cap = 65535;
+  if (cap < 1) cap = 1;
+  int64_t y = units < cap ? units : cap;
+  return (unsigned)(y < 1 ? 1 : y);
+}
+
+template <typename Pipe, typename TIn, typename TOut>
+void launch_hpass(const TIn *in, TOut *out, const char *table, int64_t rows, int W, int oW, int inner, int ksize, hipStream_t stream) {
+  if (rows <= 0 || oW <= 0) return;
+  constexpr int R = 4;
+  if (ksize >= 9 && (inner == 1 || inner == 3 || inner == 4)) {  // wide windows: a thread per pixel, four elements per load
+    const int bs = oW >= 256 ? 256 : (oW + 63) / 64 * 64;
+    const unsigned gx = (unsigned)((oW + bs - 1) / bs);
+    if (inner == 1) {
+      const unsigned gy = grid_y_for((rows + 3) / 4, gx);
+      hipLaunchKernelGGL((hpass_wide<Pipe, TIn, TOut, 1, 4>), dim3(gx, gy), dim3(bs), 0, stream, in, out, table, rows, W, oW, ksize);
+    } else {
+      const unsigned gy = grid_y_for((rows + 1) / 2, gx);
+      if (inner == 3) hipLaunchKernelGGL((hpass_wide<Pipe, TIn, TOut, 3, 2>), dim3(gx, gy), dim3(bs), 0, stream, in, out, table, rows, W, oW, ksize);
+      else hipLaunchKernelGGL((hpass_wide<Pipe, TIn, TOut, 4, 2>), dim3(gx, gy), dim3(bs), 0, stream, in, out, table, rows, W, oW, ksize);
+    }
+    return;
+  }
+  const int ncol = oW * inner;
+  const int bs = ncol >= 256 ? 256 : (ncol + 63) / 64 * 64;
+  const unsigned gx = (unsigned)((ncol + bs - 1) / bs);
+  const unsigned gy = grid_y_for((rows + R - 1) / R, gx);
+  hipLaunchKernelGGL((hpass_generic<Pipe, TIn, TOut, R>), dim3(gx, gy), dim3(bs), 0, stream, in, out, table, rows, W, oW, inner, ksize);
+}
+
+template <typename Pipe, typename TIn, typename TOut>
+void launch_vpass(const TIn *mid, TOut *out, const char *table, int64_t planes, int H, int oH, int64_t rowlen, int ksize,
+                  hipStream_t stream) {
+  if (planes <= 0 || oH <= 0 || rowlen <= 0) return;
+  // 4 elements per lane when every row start is aligned for it and the rows are long enough to keep the lanes busy
+  const bool vec4 = rowlen % 4 == 0 && rowlen >= 256 && ((uintptr_t)mid % (4 * sizeof(TIn))) == 0 &&
+                    ((uintptr_t)out % (4 * sizeof(TOut))) == 0;
+  const int vec = vec4 ? 4 : 1;
+  const unsigned gx = (unsigned)((rowlen + 64 * vec - 1) / (64 * vec));
+  const unsigned gy = grid_y_for((planes * oH + 3) / 4, gx);
+  if (vec4)
+    hipLaunchKernelGGL((vpass_generic<Pipe, TIn, TOut, 4>), dim3(gx, gy), dim3(64, 4), 0, stream, mid, out, table, planes, H, oH, rowlen, ksize);
+  else
+    hipLaunchKernelGGL((vpass_generic<Pipe, TIn, TOut, 1>), dim3(gx, gy), dim3(64, 4), 0, stream, mid, out, table, planes, H, oH, rowlen, ksize);
 }
 
 inline int grid_for(int64_t total) {
@@ -134,16 +318,14 @@ int run_two_pass(const AAProblem &p) {
   const int64_t N = p.N, C = p.C, H = p.H, W = p.W, oH = p.oH, oW = p.oW;
   const bool nhwc = p.layout == AA_NHWC;
   const int inner = nhwc ? (int)C : 1;
+  if (oW * inner > 0x7FFFFFFF || W * inner > 0x7FFFFFFF) return AA_ERR_BAD_SHAPE;
   const int64_t hrows = nhwc ? N * H : N * C * H;
-  const int64_t htotal = hrows * oW * inner;
   TMid *mid = (TMid *)p.ws;
-  hipLaunchKernelGGL((hpass_generic<Pipe, TIn, TMid>), dim3(grid_for(htotal)), dim3(256), 0, p.stream, (const TIn *)p.in,
-                     mid, (const char *)p.aw.table_dev, htotal, (int)W, (int)oW, inner, p.aw.ksize);
+  launch_hpass<Pipe, TIn, TMid>((const TIn *)p.in, mid, (const char *)p.aw.table_dev, hrows, (int)W, (int)oW, inner, p.aw.ksize, p.stream);
   const int64_t planes = nhwc ? N : N * C;
   const int64_t rowlen = nhwc ? oW * C : oW;
-  const int64_t vtotal = planes * oH * rowlen;
-  hipLaunchKernelGGL((vpass_generic<Pipe, TMid, TOut>), dim3(grid_for(vtotal)), dim3(256), 0, p.stream, (const TMid *)mid,
-                     (TOut *)p.out, (const char *)p.ah.table_dev, vtotal, (int)H, (int)oH, rowlen, p.ah.ksize);
+  launch_vpass<Pipe, TMid, TOut>((const TMid *)mid, (TOut *)p.out, (const char *)p.ah.table_dev, planes, (int)H, (int)oH, rowlen,
+                                 p.ah.ksize, p.stream);
   AA_HIP_CHECK_LAUNCH();
   return AA_OK;
 }
@@ -231,10 +413,10 @@ int aa_launch_generic_convert(const AAProblem &p, const char **variant) {
   const bool nhwc = p.layout == AA_NHWC;
   const int inner = nhwc ? (int)C : 1;
   const int64_t hrows = nhwc ? N * H : N * C * H;
-  const int64_t htotal = hrows * oW * inner;
+  if (oW * inner > 0x7FFFFFFF || W * inner > 0x7FFFFFFF) return AA_ERR_BAD_SHAPE;
   float *mid = (float *)p.ws;
-  hipLaunchKernelGGL((hpass_generic<PipeF32, uint8_t, float>), dim3(grid_for(htotal)), dim3(256), 0, p.stream,
-                     (const uint8_t *)p.in, mid, (const char *)p.aw.table_dev, htotal, (int)W, (int)oW, inner, p.aw.ksize);
+  launch_hpass<PipeF32, uint8_t, float>((const uint8_t *)p.in, mid, (const char *)p.aw.table_dev, hrows, (int)W, (int)oW, inner, p.aw.ksize,
+                                        p.stream);
   ConvertArgs cv;
   cv.in_nhwc = nhwc; cv.out_nhwc = p.out_layout == AA_NHWC; cv.normalize = p.normalize;
   for (int i = 0; i < 4; i++) { cv.mean[i] = p.mean[i]; cv.std[i] = p.std[i]; }
@@ -251,8 +433,7 @@ template <typename Pipe, typename T>
 static int run_axis(const void *in, void *out, int64_t outer, int64_t in_size, int64_t inner, const aa_axis &ax, hipStream_t stream) {
   const int64_t total = outer * ax.out_size * inner;
   if (total == 0) return AA_OK;
-  hipLaunchKernelGGL((vpass_generic<Pipe, T, T>), dim3(grid_for(total)), dim3(256), 0, stream, (const T *)in, (T *)out,
-                     (const char *)ax.table_dev, total, (int)in_size, (int)ax.out_size, inner, ax.ksize);
+  launch_vpass<Pipe, T, T>((const T *)in, (T *)out, (const char *)ax.table_dev, outer, (int)in_size, (int)ax.out_size, inner, ax.ksize, stream);
   AA_HIP_CHECK_LAUNCH();
   return AA_OK;
 }

@@ -936,3 +936,46 @@ def test_fuzz_vs_oracle_small(aa):
             exp = oracle.harness_u8(filt, x, (oh, ow))
             got = _fn(aa, filt)(_gpu(x, cl), [oh, ow], uint8_mode="harness").cpu().numpy()
         assert np.array_equal(got, exp), (it, kind, filt, (n, c, h, w), (oh, ow), cl)
+
+
+# ------------------------------------------------------------------------------------------------ generic path, wide windows
+def test_generic_wide_windows_vs_oracle(aa):
+    """Strong down-scaling (17 .. 120 taps) lands in the generic two-launch path, whose horizontal pass then reads the window four
+    elements per load (1, 3 or 4 interleaved channels) and whose vertical pass works a row per wave: bit-exact against the oracle
+    for every dtype / arithmetic, both layouts, channel counts with and without the wide kernel, windows clipped at both borders
+    (output sizes of 1 .. 3), and row counts that are not a multiple of the rows a thread walks at a time."""
+    from interpolate_antialiasing_amd import _lib
+
+    rng = np.random.default_rng(5)
+    cases = [  # (C, channels_last, filter, (N, H, W), (oH, oW))
+        (3, False, "cubic", (2, 41, 400), (9, 13)),
+        (3, True, "linear", (2, 37, 500), (11, 17)),
+        (4, True, "cubic", (1, 53, 301), (7, 10)),
+        (1, False, "linear", (3, 33, 257), (3, 2)),
+        (2, True, "cubic", (1, 30, 300), (5, 9)),      # 2 channels: the per-element kernel
+        (5, True, "linear", (1, 19, 333), (4, 21)),
+        (3, True, "box", (1, 45, 640), (6, 16)),
+        (3, False, "linear", (1, 7, 1000), (1, 1)),
+        (3, True, "cubic", (2, 300, 31), (10, 40)),     # wide windows in H only (W grows)
+    ]
+    generic = 0
+    for c, cl, filt, (n, h, w), (oh, ow) in cases:
+        f = _fn(aa, filt)
+        xf = (rng.random((n, c, h, w)) * 300 - 40).astype(np.float32)
+        xu = rng.integers(0, 256, (n, c, h, w), dtype=np.uint8)
+        got = f(_gpu(xf, cl), [oh, ow])
+        generic += _lib.last_variant().startswith("generic")
+        assert np.array_equal(got.cpu().numpy(), oracle.forward(filt, xf, (oh, ow))), ("f32", c, cl, filt, (n, h, w), (oh, ow))
+        xd = xf.astype(np.float64) * 1.000001
+        assert np.array_equal(f(_gpu(xd, cl), [oh, ow]).cpu().numpy(), oracle.forward(filt, xd, (oh, ow))), ("f64", c, cl, filt)
+        got = f(_gpu(xu, cl), [oh, ow])
+        generic += _lib.last_variant().startswith("generic")
+        assert np.array_equal(got.cpu().numpy(), oracle.pil_resize_u8(filt, xu, (oh, ow))), ("pil", c, cl, filt, (n, h, w), (oh, ow))
+        got = f(_gpu(xu, cl), [oh, ow], uint8_mode="harness")
+        assert np.array_equal(got.cpu().numpy(), oracle.harness_u8(filt, xu, (oh, ow))), ("harness", c, cl, filt)
+        for dt in (torch.float16, torch.bfloat16):  # 16-bit floats: fp32 arithmetic on the widened input, one rounding at the end
+            xh = torch.from_numpy(xf).to(dt)
+            exp = torch.from_numpy(oracle.forward(filt, xh.float().numpy(), (oh, ow))).to(dt)
+            xg = xh.cuda().contiguous(memory_format=torch.channels_last) if cl else xh.cuda()
+            assert torch.equal(f(xg, [oh, ow]).cpu(), exp), (str(dt), c, cl, filt)
+    assert generic >= 12, generic  # (most of these shapes have no fused kernel: that is the point)
