@@ -256,6 +256,50 @@ vpass_generic(const TIn *__restrict__ mid, TOut *__restrict__ out, const char *_
   }
 }
 
+// Short rows (fewer than 256 elements): a wave per output row would leave most lanes idle, so here a thread owns one element
+// (oy, e) of the output plane and walks the planes R at a time, like hpass_generic walks rows: the window and weights are read
+// once per R planes, the R planes' taps are independent loads, and consecutive threads store consecutive elements.
+template <typename Pipe, typename TIn, typename TOut, int R>
+__global__ void __launch_bounds__(256)
+vpass_short(const TIn *__restrict__ mid, TOut *__restrict__ out, const char *__restrict__ table, int64_t planes, int H, int oH,
+            int rowlen, int ksize) {
+  using WT = typename Pipe::W;
+  using Acc = typename Pipe::Acc;
+  const TableView<WT> tv = make_table_view<WT>(table, oH, ksize);
+  const int plane_elems = oH * rowlen;  // (< 2^31: checked on the host)
+  int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const bool active = idx < plane_elems;
+  idx = active ? idx : 0;
+  const int oy = idx / rowlen;
+  const int e = idx - oy * rowlen;
+  const int ymin = tv.xmin[oy];
+  int n = tv.xsize[oy];
+  n = n > 1 ? n : 1;
+  const WT *__restrict__ w = tv.w + (size_t)oy * ksize;
+  const int64_t in_plane = (int64_t)H * rowlen;
+  const TIn *__restrict__ col_src = mid + (int64_t)ymin * rowlen + e;
+  for (int64_t p0 = (int64_t)blockIdx.y * R; p0 < planes; p0 += (int64_t)gridDim.y * R) {
+    const TIn *src[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) src[r] = col_src + (p0 + r < planes ? p0 + r : planes - 1) * in_plane;
+    Acc acc[R];
+    const WT w0 = w[0];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = Pipe::first(src[r][0], w0);
+    for (int j = 1; j < n; j++) {
+      const WT wj = w[j];
+      const int64_t off = (int64_t)j * rowlen;
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] = Pipe::next(acc[r], src[r][off], wj);
+    }
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (p0 + r < planes) out[(p0 + r) * plane_elems + idx] = Store<TOut, Acc>::cvt(acc[r], 0);
+    }
+  }
+}
+
 // rows of a pass spread over grid.y, at most 65535 workgroups there and about 32 workgroups per CU in all
 inline unsigned grid_y_for(int64_t units, unsigned grid_x) {
   int64_t cap = (256 * 32 + grid_x - 1) / grid_x;
@@ -293,16 +337,34 @@ template <typename Pipe, typename TIn, typename TOut>
 void launch_vpass(const TIn *mid, TOut *out, const char *table, int64_t planes, int H, int oH, int64_t rowlen, int ksize,
                   hipStream_t stream) {
   if (planes <= 0 || oH <= 0 || rowlen <= 0) return;
-  // 4 elements per lane when every row start is aligned for it and the rows are long enough to keep the lanes busy
-  const bool vec4 = rowlen % 4 == 0 && rowlen >= 256 && ((uintptr_t)mid % (4 * sizeof(TIn))) == 0 &&
-                    ((uintptr_t)out % (4 * sizeof(TOut))) == 0;
-  const int vec = vec4 ? 4 : 1;
-  const unsigned gx = (unsigned)((rowlen + 64 * vec - 1) / (64 * vec));
+  if (rowlen < 256 && (int64_t)oH * rowlen <= 0x7FFFFFFF) {  // short rows: a thread per element, planes walked 4 (or 1) at a time
+    const int plane_elems = (int)(oH * rowlen);
+    const unsigned gx = (unsigned)((plane_elems + 255) / 256);
+    if (planes >= 4) {
+      const unsigned gy = grid_y_for((planes + 3) / 4, gx);
+      hipLaunchKernelGGL((vpass_short<Pipe, TIn, TOut, 4>), dim3(gx, gy), dim3(256), 0, stream, mid, out, table, planes, H, oH, (int)rowlen, ksize);
+    } else {
+      const unsigned gy = grid_y_for(planes, gx);
+      hipLaunchKernelGGL((vpass_short<Pipe, TIn, TOut, 1>), dim3(gx, gy), dim3(256), 0, stream, mid, out, table, planes, H, oH, (int)rowlen, ksize);
+    }
+    return;
+  }
+  // 16 bytes of input per lane (4 floats; 16 bytes of a uint8 intermediate) when every row start is aligned for it and the rows
+  // are long enough to keep the lanes busy; then 4 elements per lane; otherwise one
+  auto fits = [&](int vw) {
+    return rowlen % vw == 0 && rowlen >= 64 * vw && ((uintptr_t)mid % (vw * sizeof(TIn))) == 0 && ((uintptr_t)out % (vw * sizeof(TOut))) == 0;
+  };
+  const int vw = (sizeof(TIn) == 1 && fits(16)) ? 16 : (fits(4) ? 4 : 1);
+  const unsigned gx = (unsigned)((rowlen + 64 * vw - 1) / (64 * vw));
   const unsigned gy = grid_y_for((planes * oH + 3) / 4, gx);
-  if (vec4)
+  if (vw == 16) {
+    if constexpr (sizeof(TIn) == 1)
+      hipLaunchKernelGGL((vpass_generic<Pipe, TIn, TOut, 16>), dim3(gx, gy), dim3(64, 4), 0, stream, mid, out, table, planes, H, oH, rowlen, ksize);
+  } else if (vw == 4) {
     hipLaunchKernelGGL((vpass_generic<Pipe, TIn, TOut, 4>), dim3(gx, gy), dim3(64, 4), 0, stream, mid, out, table, planes, H, oH, rowlen, ksize);
-  else
+  } else {
     hipLaunchKernelGGL((vpass_generic<Pipe, TIn, TOut, 1>), dim3(gx, gy), dim3(64, 4), 0, stream, mid, out, table, planes, H, oH, rowlen, ksize);
+  }
 }
 
 inline int grid_for(int64_t total) {

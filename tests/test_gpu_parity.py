@@ -957,6 +957,10 @@ def test_generic_wide_windows_vs_oracle(aa):
         (3, True, "box", (1, 45, 640), (6, 16)),
         (3, False, "linear", (1, 7, 1000), (1, 1)),
         (3, True, "cubic", (2, 300, 31), (10, 40)),     # wide windows in H only (W grows)
+        (3, False, "linear", (1, 20, 300), (45, 1040)),  # growing heights, long rows: 16 uint8 / 4 floats per lane in the vertical pass
+        (1, False, "cubic", (1, 9, 40), (30, 50)),       # short rows, fewer than 4 planes
+        (3, False, "linear", (2, 12, 500), (33, 100)),   # short rows, planes walked 4 at a time (6 planes: a ragged last group)
+        (3, True, "cubic", (1, 14, 900), (40, 120)),     # rows of 360 elements: 4 per lane, not 16
     ]
     generic = 0
     for c, cl, filt, (n, h, w), (oh, ow) in cases:

@@ -45,6 +45,20 @@ elif name == "bwd":
 elif name == "up":
     x = torch.rand(64, 3, 438, 906, device=dev) * 255
     fn = lambda: aa.linear_forward(x, [1200, 1200])
+elif name.startswith("custom:"):  # custom:<u8|u8h|f32|f16>:<nchw|nhwc>:<linear|cubic>:<oW>:<oH>:<B>   (input 438x906x3)
+    _, dt, lay, filt, ow, oh, b = name.split(":")
+    x = torch.randint(0, 256, (int(b), 438, 906, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+    if lay == "nchw":
+        x = x.contiguous()
+    kw = {}
+    if dt == "u8h":
+        kw["uint8_mode"] = "harness"
+    elif dt == "f32":
+        x = x.float()
+    elif dt == "f16":
+        x = x.half()
+    op = aa.linear_forward if filt == "linear" else aa.cubic_forward
+    fn = lambda: op(x, [int(oh), int(ow)], **kw)
 else:
     raise SystemExit("unknown workload " + name)
 for _ in range(launches):
