@@ -338,7 +338,10 @@ int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *wo
   if (rc != AA_OK) return rc;
   rc = check_dtype_kind(dtype, ax_h->kind, ax_w->kind);
   if (rc != AA_OK) return rc;
-  if (N == 0) return AA_OK;
+  if (N == 0) {
+    g_last_variant = "empty";
+    return AA_OK;
+  }
   if (!grad_out_dev || !grad_in_dev) return AA_ERR_NULL;
   const size_t need = aa_workspace_bytes_bwd(dtype, layout, N, C, H, W, ax_h->out_size, ax_w->out_size);
   if (!workspace_dev || workspace_bytes < need) return AA_ERR_WORKSPACE;
@@ -348,7 +351,9 @@ int aa_resample_bwd_atomic(const void *grad_out_dev, void *grad_in_dev, void *wo
   p.N = N; p.C = C; p.H = H; p.W = W; p.oH = ax_h->out_size; p.oW = ax_w->out_size;
   p.ah = *ax_h; p.aw = *ax_w;
   p.stream = (hipStream_t)stream;
-  return aa_launch_bwd_atomic(p);
+  rc = aa_launch_bwd_atomic(p);
+  if (rc == AA_OK) g_last_variant = "bwd_scatter_atomics";
+  return rc;
 }
 
 int aa_resample_axis_fwd(const void *in_dev, void *out_dev, int dtype, int64_t outer, int64_t in_size, int64_t inner,
