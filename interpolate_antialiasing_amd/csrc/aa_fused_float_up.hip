@@ -38,6 +38,9 @@
 #ifndef AA_UP_DMA_AUX
 #define AA_UP_DMA_AUX 0    // cache-policy bits of the staging DMA (developer knob; nt loads are slower: neighbouring strips and bands re-read rows)
 #endif
+#ifndef AA_UP_PACE
+#define AA_UP_PACE 4  // rows between two pacing barriers of a workgroup whose strips share partial sectors (0: none)
+#endif
 #ifndef AA_UP_ABL
 #define AA_UP_ABL 0  // developer ablations (wrong results): 1 no output stores, 2 no input (no DMA, no horizontal pass), 3 stores
                      // of every output row land on row 0 (stay in cache)
@@ -52,6 +55,7 @@ struct FusedF32UpParams {
   int ksize_w, ksize_h;
   int ybands, nstrips, strips_per_block, strip_w;
   int nseg, seg_bytes;
+  int pace_all;    // experiment: pacing barrier whatever the store mode
   int store_nt;    // output far larger than the caches: wide stores with the streaming (nt) policy.  This path writes 6x what it
                    // reads; with the default policy the written lines push the input rows (re-read by neighbouring strips and
                    // bands) out of L2 / the Infinity Cache and reads queue behind writes: measured -33 % (row pitch a multiple of
@@ -260,7 +264,13 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   };
 
   VRow cur = load_vrow(oy0);
+  // Rows that are not whole sectors: the strips of a row (the waves of this workgroup) are kept within AA_UP_PACE rows of each
+  // other, so that the two halves of a shared end sector reach the L2 close together and leave it as one full write
+  // (906-wide gradients: 0.345 -> 0.312 ms).  Only workgroups all of whose waves are alive take the barrier.
+  const bool pace = AA_UP_PACE != 0 && (p.store_nt == 2 || p.pace_all) && p.strips_per_block > 1 &&
+                    ((k % sgroups) + 1) * p.strips_per_block <= p.nstrips;  // every wave of this workgroup is alive
   for (int oy = oy0; oy < oy1; oy++) {
+    if (pace && ((oy - oy0) % AA_UP_PACE) == 0) __builtin_amdgcn_s_barrier();
     const VRow nxt = load_vrow(oy + 1);
     int s = cur.s > 1 ? cur.s : 1;
     s = s < KR ? s : KR;
@@ -343,11 +353,23 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   }
 }
 
-int pick_ybands_up(int64_t items_per_band, double slots, int taps_h, int64_t H, int64_t oH) {
+int pick_ybands_up(int64_t items_per_band, int waves_per_item, double slots, int taps_h, int64_t H, int64_t oH) {
   // a band re-reads ~taps_h input rows; input rows are the cheap side here, so only the round efficiency matters much
   const int64_t max_yb = oH / 16 > 1 ? oH / 16 : 1;
   int64_t ybands = 1;
   double best = 1e30;
+  // Single-strip workgroups whose whole problem fits the chip in about one round: this write-bound kernel is fastest with
+  // about 20 waves per CU in flight, not with every slot filled over several rounds (measured on one box,
+  // [64,3,438,906] -> 1200x1200: 7.5 waves per CU 0.32 ms, 15 0.304-0.319, 19 0.297-0.313, 24 x 3 rounds 0.327-0.344).  Workgroups
+  // of several strips (906-wide gradients: 4 strips with the pacing barrier) measured best with the round model below.
+  const double target_waves = 20.0 * aa_device_cu_count();
+  const double waves_per_band = (double)items_per_band * waves_per_item;
+  if (waves_per_item == 1 && waves_per_band <= target_waves * 1.25 && !getenv("AA_FUSED_YBANDS")) {
+    int64_t yb = (int64_t)(target_waves / (waves_per_band > 0 ? waves_per_band : 1) + 0.5);
+    yb = yb < 1 ? 1 : (yb > max_yb ? max_yb : yb);
+    if (yb > 64) yb = 64;
+    return (int)yb;
+  }
   for (int64_t yb = 1; yb <= max_yb && yb <= 64; yb++) {
     const double rounds = (double)items_per_band * yb / slots;
     const double eff = rounds / ceil(rounds);
@@ -380,16 +402,23 @@ int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
   };
   // strips of a band share a workgroup unless single-strip workgroups put more waves on a CU (see aa_fused_u8_v3_impl.h)
   int spb = p.strips_per_block;
+  if (const char *e = getenv("AA_UP_SPB")) {  // experiment knob
+    const int v = atoi(e);
+    if (v >= 1 && v <= 8) spb = v;
+  }
   if (spb > 1 && (resident(spb) < 0 || resident(1) > resident(spb) * spb)) spb = 1;
   p.strips_per_block = spb;
   const int sgroups = (p.nstrips + spb - 1) / spb;
   const size_t lds_blk = lds * spb;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   const int64_t planes = q.N * q.C;
-  p.ybands = pick_ybands_up(planes * sgroups, (double)aa_device_cu_count() * resident(spb), taps_h, q.H, q.oH);
+  p.ybands = pick_ybands_up(planes * sgroups, spb, (double)aa_device_cu_count() * resident(spb), taps_h, q.H, q.oH);
   p.n_groups = planes * (int64_t)p.ybands;
   const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
+  if (getenv("AA_UP_DEBUG"))
+    fprintf(stderr, "up: U=%d KR=%d CPL=%d nstrips=%d spb=%d resident=%d ybands=%d groups=%lld grid=%lld lds=%zu nt=%d\n", U, KR, CPL, p.nstrips, spb,
+            resident(spb), p.ybands, (long long)p.n_groups, (long long)grid, lds_blk, p.store_nt);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, (const float *)q.in, (float *)q.out,
                      (const char *)q.aw.table_dev, (const char *)q.ah.table_dev, p);
   AA_HIP_CHECK_LAUNCH();
@@ -475,6 +504,7 @@ int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   // rows or planes that are not whole 64-byte sectors: stream only the whole sectors of each piece (see the store)
   if (p.store_nt && g.cpl == 4 && ((((uintptr_t)q.out) | (uint64_t)q.oW * 4u | p.plane_out_bytes) & 63u) != 0 && !getenv("AA_UP_NO_SPLIT"))
     p.store_nt = 2;
+  p.pace_all = getenv("AA_UP_PACE_ALL") ? 1 : 0;
   p.ybands = 1;
   p.n_groups = 0;
   const size_t lds = (size_t)AA_UP_G * p.seg_bytes;
