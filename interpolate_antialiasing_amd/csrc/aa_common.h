@@ -21,9 +21,9 @@ __host__ __device__ inline size_t aa_table_w_off(int64_t out) {
 __host__ __device__ inline size_t aa_table_weights_end(int kind, int64_t out, int ksize) {
   return aa_align16(aa_table_w_off(out) + (size_t)out * (size_t)ksize * aa_weight_elem_bytes(kind));
 }
-// gather section (AA_TABLE_F32 tables, forward and transposed): one 32-byte record per OUTPUT index
-// {xmin, xsize, w[0..5]} — a table row in one scalar load for kernels whose vertical pass gathers (aa_fused_float_up.hip)
-__host__ __device__ inline size_t aa_table_gather_bytes(int kind, int64_t out) { return kind == AA_TABLE_F32 ? 32 * (size_t)out : 0; }
+// gather section (AA_TABLE_F32 and AA_TABLE_PIL tables; F32 also transposed): one 32-byte record per OUTPUT index
+// {xmin, xsize, w[0..5]} — a table row in one scalar load for kernels whose vertical pass gathers (aa_fused_float_up.hip, the UPK mode of aa_fused_u8_v3_impl.h)
+__host__ __device__ inline size_t aa_table_gather_bytes(int kind, int64_t out) { return (kind == AA_TABLE_F32 || kind == AA_TABLE_PIL) ? 32 * (size_t)out : 0; }
 __host__ __device__ inline size_t aa_table_total_bytes(int kind, int64_t out, int ksize) {
   return aa_table_weights_end(kind, out, ksize) + aa_table_gather_bytes(kind, out);
 }
@@ -105,6 +105,13 @@ bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t N, int64_t C,
 // kernel MEASURED (header.span64p1; explicit scale factors and align_corners make it differ from 63 * in / out).
 // -1 = unknown (a caller that did not fill aa_axis.span64p1): the fused kernels decline.
 inline int aa_strip_span_px(const aa_axis &aw, int tw) { return aw.span64p1 > 0 ? aw.span64p1 + tw : -1; }
+// the same for a strip of 32 outputs: 31 steps are at most 11 runs of 3 steps, each bounded by the measured spread of 4
+// neighbouring window starts (span4p1), and never more than the spread of 64
+inline int aa_strip_span_px32(const aa_axis &aw, int tw) {
+  if (aw.span64p1 <= 0 || aw.span4p1 <= 0) return -1;
+  const int by4 = 11 * (aw.span4p1 - 1) + 1;
+  return (by4 < aw.span64p1 ? by4 : aw.span64p1) + tw;
+}
 // (row bands never exceed 64, so a grid of `units * 64` workgroups bounds every launch)
 inline bool aa_grid_fits(int64_t units) { return units > 0 && units <= (int64_t)0x7FFFFFFF / 64 - 8; }
 // CU count of the current device (cached); 256 on MI355X

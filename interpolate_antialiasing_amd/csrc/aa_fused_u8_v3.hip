@@ -5,7 +5,8 @@
 
 // Everything the kernel needs that can be known without the pointers (aa_workspace_bytes asks before they exist).
 static bool v3_shape_ok(int dtype, int layout, int64_t N, int64_t Cin, int64_t H, int64_t W, const aa_axis &ah, const aa_axis &aw, bool *flt_out,
-                        bool *planar_out, int *tw_out, int out_f32 = 0, int out_layout = AA_NCHW) {
+                        bool *planar_out, int *tw_out, int out_f32 = 0, int out_layout = AA_NCHW, bool *up_out = nullptr,
+                        int *cap_out = nullptr) {
   if (dtype != AA_U8) return false;
   if (out_f32 && (ah.kind != AA_TABLE_F32 || aw.kind != AA_TABLE_F32)) return false;  // float output = float arithmetic
   const bool flt = ah.kind == AA_TABLE_F32 && aw.kind == AA_TABLE_F32;  // the reference harness's uint8 semantics
@@ -18,22 +19,44 @@ static bool v3_shape_ok(int dtype, int layout, int64_t N, int64_t Cin, int64_t H
   if (out_f32 && planar && Cin != 1 && out_layout != AA_NCHW) return false;
   const int64_t oH = ah.out_size, oW = aw.out_size;
   if (out_f32 && (uint64_t)oH * oW * (planar ? 1 : Cin) * 4 > 0xFFFFFFF0ull) return false;
-  // the in-register vertical pass needs the H table's scatter section and at most 4 open output rows
-  if (ah.scatter_off <= 0 || ah.scatter_max <= 0 || ah.scatter_max > 4) return false;
-  if (H < oH) return false;  // down-scaling (or equal) in H: output rows complete one at a time, in order
+  const bool up = H < oH;  // growing heights: the vertical pass gathers (template parameter UPK of the kernel)
+  if (up) {  // needs the H table's gather records (6 weights each)
+    const int taps_h = ah.max_taps > 0 ? ah.max_taps : ah.ksize;
+    if (ah.gather_off <= 0 || taps_h > 6) return false;
+    // planar bytes store 64-byte pieces per strip and output row: with many strips the generic two-launch path is faster
+    // (measured, [128,3,438,906] -> 1200x1200: fused 1.14 ms, generic 0.64 ms; -> 120 columns: fused 0.123, generic 0.148)
+    if (planar && oW > 256) return false;
+  } else {  // the in-register scatter pass needs the H table's scatter section and at most 4 open output rows
+    if (ah.scatter_off <= 0 || ah.scatter_max <= 0 || ah.scatter_max > 4) return false;
+  }
   const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
   int tw = round_tw(taps_w);
   if (flt && tw != 0 && tw < 6) tw = 6;  // the float variant is instantiated for windows of 6, 8 and 12 taps
   if (flt && tw > 12) return false;
   if (tw == 0 || W < tw) return false;
   if ((uint64_t)H * W * C > 0xFFFFFFF0ull || (uint64_t)oH * oW * C > 0xFFFFFFF0ull) return false;
-  const int span_px = aa_strip_span_px(aw, tw);
+  int span_px = aa_strip_span_px(aw, tw);
   if (span_px < 0) return false;
-  const int nseg = (span_px * C + 3 + 15 + 15) / 16;
+  int nseg = (span_px * C + 3 + 15 + 15) / 16;
+  int cap = 64;  // output columns per strip
+  if (up && nseg > 64) {
+    // the gather form is instantiated with one staging DMA per row (64 pieces): strong down-scaling in W (test.py's 906 -> 120
+    // with growing heights) gets strips of 32 columns — half the lanes idle, but such a shape is bound by its input stream
+    span_px = aa_strip_span_px32(aw, tw);
+    if (span_px < 0) return false;
+    nseg = (span_px * C + 3 + 15 + 15) / 16;
+    cap = 32;
+    if (nseg > 64) return false;
+    // ... unless the first-generation kernel (Pillow arithmetic, channels_last, uint8 out) takes the shape: its block-wide tiles
+    // handle these wide windows better (measured, [128,3,438,906] -> 1200 x 120: 0.060 ms against 0.095 ms here)
+    if (!flt && !planar && !out_f32 && aa_fused_u8_nhwc_applicable(dtype, layout, N, Cin, H, W, &ah, &aw)) return false;
+  }
   if (nseg > 128 || (size_t)aa_v3_group() * nseg * 16 > 64 * 1024) return false;
-  const int64_t nstrips = (oW + 63) / 64 + 1;  // (balanced strips can be one more)
+  const int64_t nstrips = (oW + cap - 1) / cap + 1;  // (balanced strips can be one more)
   if (!aa_grid_fits((planar ? N * Cin : N) * nstrips)) return false;
   *flt_out = flt; *planar_out = planar; *tw_out = tw;
+  if (up_out) *up_out = up;
+  if (cap_out) *cap_out = cap;
   return true;
 }
 
@@ -45,9 +68,9 @@ bool aa_fused_u8_v3_applicable(int dtype, int layout, int64_t N, int64_t C, int6
 }
 
 int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
-  bool flt, planar;
-  int tw;
-  if (!v3_shape_ok(q.dtype, q.layout, q.N, q.C, q.H, q.W, q.ah, q.aw, &flt, &planar, &tw, q.out_f32, q.out_layout)) return 0;
+  bool flt, planar, up = false;
+  int tw, cap = 64;
+  if (!v3_shape_ok(q.dtype, q.layout, q.N, q.C, q.H, q.W, q.ah, q.aw, &flt, &planar, &tw, q.out_f32, q.out_layout, &up, &cap)) return 0;
   const int C = planar ? 1 : (int)q.C;
   const int64_t NI = planar ? q.N * q.C : q.N;  // images the kernel sees
   const int G = aa_v3_group();
@@ -68,7 +91,8 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   p.total_out_bytes = p.img_out_bytes * (unsigned long long)NI;
   p.n_images = NI;
   p.sc_off = q.ah.scatter_off;
-  p.nstrips = (int)((q.oW + 63) / 64);
+  p.gather_off = q.ah.gather_off;
+  p.nstrips = (int)((q.oW + cap - 1) / cap);
   p.strip_w = (int)(((q.oW + p.nstrips - 1) / p.nstrips + 3) & ~3);  // balanced strips (196 -> 4 x 52, not 3 x 64 + 4)
   p.nstrips = (int)((q.oW + p.strip_w - 1) / p.strip_w);
   // all strips of a band in one workgroup when they fit (<= 8 waves); wider images: groups of 4 strips
@@ -80,7 +104,7 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   }
 
   // segment: bytes covered by 64 consecutive windows of one input row (+ alignment slack), see aa_fused_u8_v2.hip
-  const int span_px = aa_strip_span_px(q.aw, tw);
+  const int span_px = cap == 32 ? aa_strip_span_px32(q.aw, tw) : aa_strip_span_px(q.aw, tw);
   p.nseg = (span_px * C + 3 + 15 + 15) / 16;
   if (p.nseg > 128) return 0;
   p.seg_bytes = p.nseg * 16;
@@ -89,9 +113,18 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
 
   p.ybands = 1;
 
-  const int rc = C == 3   ? aa_v3_launch_c3(tw, q.ah.scatter_max, flt, p, q, lds)
-                 : C == 4 ? aa_v3_launch_c4(tw, q.ah.scatter_max, flt, p, q, lds)
-                          : aa_v3_launch_c1(tw, q.ah.scatter_max, flt, p, q, lds);
+  int rc;
+  if (up) {
+    const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
+    const bool nonneg = q.aw.filter != AA_FILTER_CUBIC && q.ah.filter != AA_FILTER_CUBIC;
+    rc = C == 3   ? aa_v3_launch_up_c3(tw, taps_h, nonneg, flt, p, q, lds)
+         : C == 4 ? aa_v3_launch_up_c4(tw, taps_h, nonneg, flt, p, q, lds)
+                  : aa_v3_launch_up_c1(tw, taps_h, nonneg, flt, p, q, lds);
+  } else {
+    rc = C == 3   ? aa_v3_launch_c3(tw, q.ah.scatter_max, flt, p, q, lds)
+         : C == 4 ? aa_v3_launch_c4(tw, q.ah.scatter_max, flt, p, q, lds)
+                  : aa_v3_launch_c1(tw, q.ah.scatter_max, flt, p, q, lds);
+  }
   if (rc == 1 && q.out_f32) *variant = planar ? "fused_u8_planar_to_f32_v3" : (p.outm == 1 ? "fused_u8_nhwc_to_f32_nchw_v3" : "fused_u8_nhwc_to_f32_nhwc_v3");
   else if (rc == 1) *variant = flt ? (planar ? "fused_u8_planar_harness_v3" : "fused_u8_nhwc_harness_v3")
                         : (planar ? "fused_u8_planar_pil_v3" : "fused_u8_nhwc_pil_v3");

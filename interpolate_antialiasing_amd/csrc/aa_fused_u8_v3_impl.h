@@ -75,6 +75,7 @@ struct FusedU8V3Params {
   int nseg;        // 16-byte pieces per staged row segment (<= 128)
   int seg_bytes;   // nseg * 16
   int sc_off;      // scatter section of the H table (bytes from table start): one 8-int record per input row
+  int gather_off;  // gather section of the H table (growing heights): one 8-int record {ymin, ysize, w[6]} per output row
   int in_mis;      // (input pointer & 15): the kernel gets the pointer rounded down to 16 B
   unsigned long long img_in_bytes, img_out_bytes, total_in_bytes, total_out_bytes;
   long long n_images;  // = N for channels_last, N*C for planar input
@@ -141,7 +142,12 @@ __device__ inline void wait_vmcnt(int n) {  // rounding n DOWN only waits longer
 #else
 #define AA_V3_OCC
 #endif
-template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC, bool FLT = false>
+// UPK > 0: heights that GROW (oH > H).  An input row then feeds more output rows than a scatter record holds, so the vertical pass
+//      GATHERS: the horizontal-pass results of the last UPK input rows stay in a register ring, and every output row whose window
+//      ends at the row just filtered is the weighted sum of the ring's last `ysize` entries (weights: one scalar load of the H
+//      table's gather record, taps in order).  The row pipeline is the generic-address one; DMA completion is tracked per stage
+//      slot because the output stores (several per input row) share the in-order vmcnt counter with the DMAs.
+template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0>
 __global__ void __launch_bounds__(512) AA_V3_OCC
 fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const char *__restrict__ tab_w,
                         const char *__restrict__ tab_h, const FusedU8V3Params p) {
@@ -178,6 +184,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   const int32_t *__restrict__ ymin_h = (const int32_t *)(tab_h + aa_table_xmin_off());
   const int32_t *__restrict__ ysize_h = (const int32_t *)(tab_h + aa_table_xsize_off(p.oH));
   const int32_t *__restrict__ sc_rec = (const int32_t *)(tab_h + p.sc_off);
+  const int32_t *__restrict__ g_rec = (const int32_t *)(tab_h + p.gather_off);  // (UPK > 0 only)
 
   // input rows this band needs: [r_begin, r_stop)
   const int r_begin = __builtin_amdgcn_readfirstlane(ymin_h[oy0]);
@@ -264,8 +271,22 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     for (int c = 0; c < C; c++) A[k][c] = FLT ? 0 : 1 << 21;
   int o_base = oy0;
 
+  // gather mode: ring of the last UPK horizontal-pass results; VMEM instructions issued so far and, in lane s, their count right
+  // after the DMA that filled stage slot s
+  constexpr int RK = UPK > 0 ? UPK : 1;
+  int ring[RK][C];
+#pragma unroll
+  for (int k = 0; k < RK; k++)
+#pragma unroll
+    for (int c = 0; c < C; c++) ring[k][c] = 0;
+  int vm_issued = 0, idxv = 0;
+
   auto dma = [&](unsigned a_row, int slot) {
     if (AA_V3_ABL == 4) return;
+    if constexpr (UPK > 0) {  // (lane 0 always takes part in the DMA: the instruction is certainly issued)
+      vm_issued += TWO_DMA ? 2 : 1;
+      idxv = (lane == slot) ? vm_issued : idxv;
+    }
     if (AA_V3_PRIO) __builtin_amdgcn_s_setprio(3);
     const unsigned soff = AA_V3_ABL == 7 ? (a_row & 0x3F0u) : (a_row & ~15u);  // 7: every DMA hits the same 1.6 KB
     const int dst = lds_base + slot * p.seg_bytes;
@@ -312,6 +333,12 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   struct Scatter { int first; int cc; int w[MAXC]; };  // raw record words (nothing depends on them until they are used)
   auto load_scatter = [&](int r) -> Scatter {  // one 32-byte record: {first, count | completes << 16, w[6]}
     Scatter s;                                   // (the section has H + 1 records: r == H reads the all-zero sentinel)
+    if constexpr (UPK > 0) {  // gather mode never reads the scatter section
+      s.first = 0; s.cc = 0;
+#pragma unroll
+      for (int k = 0; k < MAXC; k++) s.w[k] = 0;
+      return s;
+    }
     const int32_t *rec = (const int32_t *)((const char *)sc_rec + (unsigned)r * 32u);
     s.first = __builtin_amdgcn_readfirstlane(rec[0]);
     s.cc = __builtin_amdgcn_readfirstlane(rec[1]);  // count | completes << 16
@@ -337,12 +364,14 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           if (p.normalize) v[c] = (v[c] - nm_mean[c]) / nm_std[c];
         }
         if (p.outm == 1) {
+          if constexpr (UPK > 0) vm_issued += C;  // (lane 0 is active: each of the C stores is certainly issued)
 #pragma unroll
           for (int c = 0; c < C; c++)
             if (active)
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[c]), orsrc, (unsigned)(ox0 + lane_o) * 4u,
                                                     ((unsigned)c * (unsigned)p.oH + (unsigned)oy) * (unsigned)p.oW * 4u, AA_V3_F32OUT_AUX);
         } else {
+          if constexpr (UPK > 0) vm_issued += 1;
           const unsigned fv = (unsigned)(ox0 + lane_o) * (unsigned)(4 * C), fs = (unsigned)oy * (unsigned)p.oW * (unsigned)(4 * C);
           if constexpr (C == 3) {
             typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
@@ -365,12 +394,16 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
                                         // costs the common path 5 VGPRs, i.e. a wave per SIMD (76 -> 81 registers)
       const unsigned bv = (unsigned)((ox0 + lane_o) * C);
       const bool act = lane_o < bw;
+      if constexpr (UPK > 0) vm_issued += C;
 #pragma unroll
       for (int c = 0; c < C; c++) {
         const unsigned b = FLT ? trunc8(A[0][c]) : (unsigned)clip8_int(A[0][c]);
         if (act) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, bv + c, (unsigned)oy * out_row_bytes, 0);
       }
       stored = true;
+    }
+    if constexpr (UPK > 0) {
+      if (!stored) vm_issued += 1;  // the dword store below: lane 0 stores whenever the strip holds a whole quad (it does)
     }
     if (stored) {
     } else if constexpr (C == 3) {
@@ -399,6 +432,24 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
     for (int c = 0; c < C; c++) A[MAXC - 1][c] = FLT ? 0 : 1 << 21;
   };
+  // gather mode: table row of an output = one scalar load of its gather record {ymin, ysize, w[6]}
+  struct GRow { int m; int s; int w[RK]; };
+  auto load_grow = [&](int oy) -> GRow {
+    GRow gr;
+    const int o = oy < p.oH ? oy : p.oH - 1;
+    const int32_t *rec = (const int32_t *)((const char *)g_rec + (unsigned)o * 32u);
+    gr.m = __builtin_amdgcn_readfirstlane(rec[0]);
+    gr.s = __builtin_amdgcn_readfirstlane(rec[1]);
+#pragma unroll
+    for (int k = 0; k < RK; k++) gr.w[k] = __builtin_amdgcn_readfirstlane(rec[2 + (k < 6 ? k : 5)]);
+    return gr;
+  };
+  GRow g_cur, g_nxt;
+  if constexpr (UPK > 0) {
+    g_cur = load_grow(oy0);
+    g_nxt = load_grow(oy0 + 1);
+  }
+  int r = r_begin;  // the input row being filtered
   // one input row: horizontal pass from the fetched window, then scatter into the open output rows
   // the window of the CURRENT row, realigned; consumes the LDS reads issued one row earlier
   auto realign = [&](const unsigned (&d)[ND], unsigned sa, unsigned (&v)[NV]) {
@@ -437,6 +488,45 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       }
 #pragma unroll
       for (int c = 0; c < C; c++) h[c] = NONNEG ? (int)((unsigned)acc[c] >> 22) : clip8_int(acc[c]);
+    }
+    if constexpr (UPK > 0) {
+      // push this row's result; then every output row whose window ends here is the sum over the ring's last `ysize` entries
+#pragma unroll
+      for (int k = 0; k + 1 < RK; k++)
+#pragma unroll
+        for (int c = 0; c < C; c++) ring[k][c] = ring[k + 1][c];
+#pragma unroll
+      for (int c = 0; c < C; c++) ring[RK - 1][c] = h[c];
+      while (o_base < oy1) {
+        int gs = g_cur.s > 1 ? g_cur.s : 1;
+        if (g_cur.m + gs != r + 1) break;  // (window ends are non-decreasing: later outputs end later)
+        gs = gs < RK ? gs : RK;
+#pragma unroll
+        for (int ss = 1; ss <= RK; ss++) {
+          if (gs == ss) {  // wave-uniform: one static unrolling runs; taps beyond the window are not added at all
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+              int acc;
+              if constexpr (FLT) {
+                float f = __int_as_float(ring[RK - ss][c]) * __int_as_float(g_cur.w[0]);
+#pragma unroll
+                for (int k2 = 1; k2 < ss; k2++) f = f + __int_as_float(ring[RK - ss + k2][c]) * __int_as_float(g_cur.w[k2]);
+                acc = __float_as_int(f);
+              } else {
+                acc = (1 << 21) + __mul24(ring[RK - ss][c], g_cur.w[0]);
+#pragma unroll
+                for (int k2 = 1; k2 < ss; k2++) acc += __mul24(ring[RK - ss + k2][c], g_cur.w[k2]);
+              }
+              A[0][c] = acc;
+            }
+          }
+        }
+        emit(o_base);
+        o_base++;
+        g_cur = g_nxt;
+        g_nxt = load_grow(o_base + 1);
+      }
+      return;
     }
     auto vmac = [&](int a, int hv, int w) -> int {  // one vertical tap
       if constexpr (FLT) return __float_as_int(__int_as_float(a) + __int_as_float(hv) * __int_as_float(w));
@@ -487,10 +577,9 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   // even) / d1 (x odd); its scatter record loaded into sc0 / sc1.  Output stores also count in vmcnt: they are
   // younger than every DMA the wait below must cover, so "at most G-2 outstanding" still implies row x+1 has landed
   // (it only waits for a few more rows than strictly necessary).
-  int r = r_begin;
   for (int g = 0; g < n_groups; g++) {
     const int x0 = g * G;
-    if (x0 + 2 * G <= n_rows) {  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
+    if (UPK == 0 && x0 + 2 * G <= n_rows) {  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
       // Not a data dependence: once per G rows the strips of a band line up, so that the 192-byte pieces they store into
       // the same output rows reach L2 within a few microseconds of each other and leave it as whole lines (measured
       // -2 %; every strip of the workgroup runs the same number of groups).
@@ -537,9 +626,14 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
         const int x = x0 + i;
         if (x >= n_rows) break;
         if (x + 1 < n_rows) {
-          int younger = n_rows - 1 - (x + 1);
-          younger = younger < G - 2 ? younger : G - 2;
-          wait_vmcnt(younger * dma_per_row);
+          if constexpr (UPK > 0) {  // everything issued up to and including the DMA of row x+1's slot has completed
+            const int my_idx = __builtin_amdgcn_readlane(idxv, __builtin_amdgcn_readfirstlane((i + 1) % G));
+            wait_vmcnt(vm_issued - my_idx);
+          } else {
+            int younger = n_rows - 1 - (x + 1);
+            younger = younger < G - 2 ? younger : G - 2;
+            wait_vmcnt(younger * dma_per_row);
+          }
           if ((i & 1) == 0) { sc1 = load_scatter(r + 1); sa1 = fetch(a + row_bytes, (i + 1) % G, d1, false); }
           else { sc0 = load_scatter(r + 1); sa0 = fetch(a + row_bytes, (i + 1) % G, d0, false); }
         }
@@ -586,9 +680,9 @@ int pick_ybands(int64_t items_per_band, double slots, int taps_h, int64_t H, int
   return (int)ybands;
 }
 
-template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC, bool FLT = false>
+template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0>
 int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
-  auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC, FLT>;
+  auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC, FLT, UPK>;
   auto resident = [&](int s) {  // resident workgroups of s strips per CU for this instantiation and this problem's LDS
     int nb = aa_resident_blocks(kern, 64 * s, lds * s);
     if (nb <= 0) nb = 16 / s;
@@ -684,6 +778,32 @@ int dispatch_tw(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, 
   return 0;
 }
 
+// growing heights (gather-form vertical pass): generic window addressing, one DMA per row, no scatter accumulators.  Ring of 2
+// rows for the triangle / box filters (never negative: the intermediate needs no clamp), of 6 for everything else.
+template <int C, int TW>
+int launch_up(int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  if (flt) {
+    if constexpr (TW >= 6 && TW <= 12)
+      return upk <= 2 ? launch_k<C, TW, 8, 1, false, false, false, true, 2>(p, q, lds, 0)
+                      : launch_k<C, TW, 8, 1, false, false, false, true, 6>(p, q, lds, 0);
+    return 0;
+  }
+  return (nonneg && upk <= 2) ? launch_k<C, TW, 8, 1, false, true, false, false, 2>(p, q, lds, 0)
+                              : launch_k<C, TW, 8, 1, false, false, false, false, 6>(p, q, lds, 0);
+}
+
+template <int C>
+int dispatch_up(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  if (flt && tw < 6) tw = 6;
+  if (tw <= 2) return launch_up<C, 2>(upk, nonneg, flt, p, q, lds);
+  if (tw <= 4) return launch_up<C, 4>(upk, nonneg, flt, p, q, lds);
+  if (tw <= 6) return launch_up<C, 6>(upk, nonneg, flt, p, q, lds);
+  if (tw <= 8) return launch_up<C, 8>(upk, nonneg, flt, p, q, lds);
+  if (tw <= 12) return launch_up<C, 12>(upk, nonneg, flt, p, q, lds);
+  if (tw <= 16) return launch_up<C, 16>(upk, nonneg, flt, p, q, lds);
+  return 0;
+}
+
 int round_tw(int taps) {
   const int opts[] = {2, 4, 6, 8, 12, 16};
   for (int o : opts)
@@ -697,3 +817,7 @@ int round_tw(int taps) {
 int aa_v3_launch_c1(int tw, int maxc, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c3(int tw, int maxc, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c4(int tw, int maxc, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+// growing heights (aa_fused_u8_v3_c{1,3,4}u.hip)
+int aa_v3_launch_up_c1(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_up_c3(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_up_c4(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);

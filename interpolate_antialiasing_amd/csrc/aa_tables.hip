@@ -286,7 +286,7 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
   h.scatter_max = 0;
   h.span64p1 = 0;
   h.span4p1 = 0;
-  h.gather_off = kind == AA_TABLE_F32 ? (int32_t)aa_table_weights_end(kind, out_size, ksize) : 0;
+  h.gather_off = (kind == AA_TABLE_F32 || kind == AA_TABLE_PIL) ? (int32_t)aa_table_weights_end(kind, out_size, ksize) : 0;
   if (scatter_ksize > 0) {
     h.scatter_off = (int32_t)aa_table_total_bytes(kind, out_size, ksize);
     h.scatter_ksize = scatter_ksize;

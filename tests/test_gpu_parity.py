@@ -983,3 +983,61 @@ def test_generic_wide_windows_vs_oracle(aa):
             xg = xh.cuda().contiguous(memory_format=torch.channels_last) if cl else xh.cuda()
             assert torch.equal(f(xg, [oh, ow]).cpu(), exp), (str(dt), c, cl, filt)
     assert generic >= 12, generic  # (most of these shapes have no fused kernel: that is the point)
+
+
+# ------------------------------------------------------------------------------------------------ uint8, heights that grow
+def test_u8_growing_heights_take_the_fused_gather_form(aa):
+    """Heights that grow (test.py's (120, 1200) and up-scaling in general): the fused uint8 kernel's vertical pass gathers over a
+    register ring of the last input rows.  Bit-exact against the oracle in Pillow and harness arithmetic, channels_last (3 / 4
+    channels) and planar, widths that grow or shrink, ragged output widths (byte stores), rows bands (many output rows), a
+    single input row, and the float32-output conversion."""
+    from interpolate_antialiasing_amd import _lib
+
+    rng = np.random.default_rng(11)
+    cases = [  # (C, channels_last, filter, (N, H, W), (oH, oW))
+        (3, True, "linear", (2, 23, 50), (61, 128)),
+        (3, True, "cubic", (2, 23, 50), (61, 128)),
+        (3, True, "box", (1, 17, 40), (50, 64)),
+        (4, True, "linear", (1, 19, 33), (47, 100)),
+        (4, True, "cubic", (1, 30, 200), (77, 64)),     # W shrinks (13 taps), H grows
+        (3, False, "linear", (1, 21, 64), (64, 200)),   # planar
+        (3, False, "linear", (1, 21, 64), (64, 300)),   # planar, more than 256 columns: the generic path by choice
+        (3, False, "cubic", (2, 9, 31), (40, 77)),      # planar, ragged width: byte stores
+        (3, True, "linear", (1, 12, 70), (100, 45)),    # ragged width, channels_last
+        (3, True, "linear", (1, 1, 16), (9, 32)),       # one input row
+        (3, True, "cubic", (1, 40, 120), (700, 132)),   # many output rows: several bands
+        (1, False, "linear", (3, 25, 906), (70, 120)),  # the harness's (120, H-up) shape class: 16-17 taps in W
+    ]
+    fused = 0
+    for c, cl, filt, (n, h, w), (oh, ow) in cases:
+        f = _fn(aa, filt)
+        x = rng.integers(0, 256, (n, c, h, w), dtype=np.uint8)
+        got = f(_gpu(x, cl), [oh, ow])
+        v = _lib.last_variant()
+        fused += v.endswith("_v3")
+        assert np.array_equal(got.cpu().numpy(), oracle.pil_resize_u8(filt, x, (oh, ow))), ("pil", v, c, cl, filt, (n, h, w), (oh, ow))
+        got = f(_gpu(x, cl), [oh, ow], uint8_mode="harness")
+        v = _lib.last_variant()
+        fused += v.endswith("_v3")
+        assert np.array_equal(got.cpu().numpy(), oracle.harness_u8(filt, x, (oh, ow))), ("harness", v, c, cl, filt, (n, h, w), (oh, ow))
+        if c in (3, 4) and cl:  # decode-adjacent conversion: uint8 HWC in, float32 NCHW out == the oracle's fp32 forward
+            got = f(_gpu(x, cl), [oh, ow], out_dtype=torch.float32, out_format="nchw")
+            exp = oracle.forward(filt, x.astype(np.float32), (oh, ow))
+            assert np.array_equal(got.cpu().numpy(), exp), ("to_f32", _lib.last_variant(), c, filt)
+    assert fused >= 18, fused
+    # at BASELINE-like size: fused == generic (two independent implementations), Pillow arithmetic, batch of 8
+    x = torch.randint(0, 256, (8, 438, 906, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
+    # (harness arithmetic: <= 12 taps in W; Pillow arithmetic at 906 -> 120 belongs to the first-generation kernel: 200 columns here)
+    for mode, sizes in (("pil", ([1200, 1200], [1200, 200])), ("harness", ([1200, 1200], [1200, 200]))):
+        for size in sizes:
+            try:
+                _lib.set_fused(1)
+                a = aa.linear_forward(x, size, uint8_mode=mode)
+                va = _lib.last_variant()
+                _lib.set_fused(0)
+                b = aa.linear_forward(x, size, uint8_mode=mode)
+                vb = _lib.last_variant()
+            finally:
+                _lib.set_fused(1)
+            assert va.endswith("_v3") and vb.startswith("generic"), (va, vb)
+            assert torch.equal(a, b), (size, mode, va, vb)
