@@ -84,7 +84,7 @@ typedef struct aa_table_header {
                             align_corners make it differ from 63*in/out); 0 = not measured */
   int32_t span4p1;       /* the same over 4 consecutive outputs: 1 + max_i (xmin[min(i+3,out-1)] - xmin[i]) (kernels in which
                             a lane computes 4 neighbouring outputs from one shared window) */
-  int32_t gather_off;    /* byte offset of the gather section (AA_TABLE_F32 tables; 0 = none): one 32-byte record per OUTPUT index,
+  int32_t gather_off;    /* byte offset of the gather section (AA_TABLE_F32 and AA_TABLE_PIL tables; 0 = none): one 32-byte record per OUTPUT index,
                             { int32 xmin, int32 xsize, float w[6] } = a table row in one scalar load (rows wider than 6 taps keep
                             their full weights in w[] above) */
   int32_t reserved[1];
@@ -125,8 +125,8 @@ int aa_device_count(void);
  * Pillow's for AA_TABLE_PIL.  scale<=0: scale derived from sizes (area_pixel_compute_scale, call site
  * s2.2:314-315).  Returns ksize (>0) or a negative aa_status. */
 int aa_table_ksize(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale);
-/* Bytes of the packed table for (kind, out_size, ksize) without a scatter section (transposed tables); AA_TABLE_F32 tables
- * include their gather section (32 bytes per output index). */
+/* Bytes of the packed table for (kind, out_size, ksize) without a scatter section (transposed tables); AA_TABLE_F32
+ * and AA_TABLE_PIL tables include their gather section (32 bytes per output index). */
 size_t aa_table_bytes(int kind, int64_t out_size, int ksize);
 /* Bytes aa_table_build() needs for this table (AA_TABLE_PIL tables carry a scatter section as well). */
 size_t aa_table_build_bytes(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale);

@@ -47,7 +47,7 @@ class WeightTable:
     scatter_max: int = 0
     span64p1: int = 0  # 1 + the widest spread of 64 consecutive outputs' window starts (measured on device; 0 = unknown)
     span4p1: int = 0   # the same over 4 consecutive outputs
-    gather_off: int = 0  # byte offset of the per-output gather records (F32 tables)
+    gather_off: int = 0  # byte offset of the per-output gather records (F32 and Pillow tables)
 
     def axis(self) -> _lib.Axis:
         if not self.buf.is_cuda:
