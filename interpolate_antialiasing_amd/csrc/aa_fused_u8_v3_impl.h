@@ -761,6 +761,7 @@ int dispatch_tw_flt(int tw, int maxc, const FusedU8V3Params &p, const AAProblem 
   if (tw <= 6) return launch_flt<C, 6>(maxc, p, q, lds, grid);
   if (tw <= 8) return launch_flt<C, 8>(maxc, p, q, lds, grid);
   if (tw <= 12) return launch_flt<C, 12>(maxc, p, q, lds, grid);
+  if (tw <= 16) return launch_flt<C, 16>(maxc, p, q, lds, grid);  // (test.py's 906 -> 120 thumbnails: 16 taps)
   return 0;
 }
 
@@ -783,7 +784,7 @@ int dispatch_tw(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, 
 template <int C, int TW>
 int launch_up(int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
   if (flt) {
-    if constexpr (TW >= 6 && TW <= 12)
+    if constexpr (TW >= 6 && TW <= 16)
       return upk <= 2 ? launch_k<C, TW, 8, 1, false, false, false, true, 2>(p, q, lds, 0)
                       : launch_k<C, TW, 8, 1, false, false, false, true, 6>(p, q, lds, 0);
     return 0;
