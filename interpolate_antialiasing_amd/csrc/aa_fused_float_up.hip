@@ -115,8 +115,11 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   if (strip >= p.nstrips) return;
   const int yb = (int)(grp % p.ybands);
   const int plane = (int)(grp / p.ybands);  // n * C + c
-  const int ox0 = strip * p.strip_w;
-  const int bw = min(p.strip_w, p.oW - ox0);
+  // store_nt == 3 (sector-aligned pieces, see the store): strips advance by 240 columns and start 16 columns early, so a wave
+  // holds every column its row-dependent 960-byte piece can need; columns outside the row are duplicates and never stored
+  const bool aln = p.store_nt == 3;
+  const int ox0 = aln ? strip * 240 - 16 : strip * p.strip_w;
+  const int bw = aln ? 256 : min(p.strip_w, p.oW - ox0);
   const int oy0 = (int)((long long)yb * p.oH / p.ybands);
   const int oy1 = (int)((long long)(yb + 1) * p.oH / p.ybands);
 
@@ -134,7 +137,8 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   // ---- per-lane horizontal-pass state: CPL outputs sharing one union window of U floats ------------------------------
   const int col0 = lane * CPL;                 // first column of the lane inside the strip
   const bool any_active = col0 < bw;
-  const int oxb = ox0 + (any_active ? col0 : 0);  // (lanes beyond the strip duplicate lane 0 and never store)
+  int oxb = ox0 + (any_active ? col0 : 0);  // (lanes beyond the strip duplicate lane 0 and never store)
+  oxb = oxb < 0 ? 0 : (oxb < p.oW ? oxb : p.oW - 1);
   int ustart;  // row position of the union window's first float
   {
     const int xm0 = xmin_w[oxb];
@@ -146,7 +150,8 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   unsigned long long inwin[CPL][U];  // lane masks (scalar registers): union position q is one of output e's own taps
 #pragma unroll
   for (int e = 0; e < CPL; e++) {
-    const int oxe = (oxb + e < p.oW) ? oxb + e : p.oW - 1;  // (columns beyond the row compute a duplicate, never stored)
+    int oxe = ox0 + col0 + e;  // (columns outside the row compute a duplicate, never stored)
+    oxe = (!any_active || oxe < 0) ? oxb : (oxe < p.oW ? oxe : p.oW - 1);
     const int xm = xmin_w[oxe];
     int xs = xsize_w[oxe];
     xs = xs > 1 ? xs : 1;  // tap 0 is unconditional in the reference (s2.2:68-73)
@@ -184,6 +189,10 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   const unsigned phase0 = (unsigned)(((unsigned long long)(uintptr_t)out + out_off + (unsigned long long)ox0 * 4u) & 127u);
 
   const unsigned a_base = (unsigned)seg0 * 4u;  // byte offset (from the plane) of the strip's segment in row 0
+  // sector-aligned pieces: this wave's 1088-byte staging area behind the workgroup's stage rings; float phase of the plane in
+  // the 64-byte sector grid
+  const unsigned aln_lds = (unsigned)(p.strips_per_block * G * p.seg_bytes + wv * 1088);
+  const unsigned phase0f = (unsigned)((((unsigned long long)(uintptr_t)out + out_off) >> 2) & 15u);
 
   // ---- staging ring bookkeeping ------------------------------------------------------------------------------------
   int vm_issued = 0;  // VMEM instructions (DMAs + stores) this wave has issued since the wait above
@@ -299,7 +308,34 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
     if constexpr (CPL == 4) {
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const u32x4 t = {__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
-      if (p.store_nt == 2 && bw >= CPL) {
+      if (aln) {
+        // Rows that are not whole 64-byte sectors, even widths: the piece a strip stores is cut at the sector boundaries of
+        // THIS row — columns [240 k - d, 240 k + 240 - d), d = the row's phase in floats (even, 0 .. 14) — so every streamed
+        // store covers whole sectors and no sector is shared between strips (only the row's two ends stay partial).  The wave
+        // holds columns 240 k - 16 .. 240 k + 239; a pass through LDS moves each lane's four results to the lane that owns
+        // their absolute 16-byte slot (8-byte aligned reads: d is even).
+        __attribute__((address_space(3))) u32x4 *stw = (__attribute__((address_space(3))) u32x4 *)(uintptr_t)(aln_lds + (unsigned)lane * 16u);
+        *stw = t;
+        const unsigned d = (phase0f + (unsigned)oy * (unsigned)p.oW) & 15u;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned rd = aln_lds + (16u - d) * 4u + (lane < 60 ? (unsigned)lane * 16u : 0u);
+        const __attribute__((address_space(3))) u32x2 *ldp = (const __attribute__((address_space(3))) u32x2 *)(uintptr_t)rd;
+        const u32x2 v0 = ldp[0], v1 = ldp[1];
+        const int colj = strip * 240 - (int)d + lane * 4;  // first column of this lane's slot
+        const bool mine = lane < 60;
+        const bool lo_ok = mine && colj >= 0 && colj + 1 < p.oW;
+        const bool hi_ok = mine && colj + 2 >= 0 && colj + 3 < p.oW;
+        const bool full = lo_ok && hi_ok;
+        const unsigned cvoff = (unsigned)(colj * 4);
+        if (__ballot(full) != 0ull) {  // (wave-uniform: the store is certainly issued and may be counted)
+          const u32x4 tv = {v0.x, v0.y, v1.x, v1.y};
+          if (full) __builtin_amdgcn_raw_buffer_store_b128(tv, orsrc, cvoff, soff, 2);
+          vm_issued++;
+        }
+        // the row's first / last slot can hold two columns only (never counted: waiting for more is safe)
+        if (lo_ok && !hi_ok) __builtin_amdgcn_raw_buffer_store_b64(v0, orsrc, cvoff, soff, 2);
+        if (hi_ok && !lo_ok) __builtin_amdgcn_raw_buffer_store_b64(v1, orsrc, cvoff + 8u, soff, 2);
+      } else if (p.store_nt == 2 && bw >= CPL) {
         // Output rows that are not whole 64-byte sectors (oW = 906: 3624 B): the sectors a piece shares with its
         // neighbouring strip are written half by each, and a streamed (nt) half-sector write costs a read-modify-write
         // at the memory.  So only the lanes whose 16 bytes lie in whole sectors of the piece stream; the lanes of its
@@ -500,14 +536,23 @@ int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   p.nseg = g.nseg;
   p.seg_bytes = p.nseg * 16;
   p.gather_off = q.ah.gather_off;
-  p.store_nt = (p.total_out_bytes > (64ull << 20) && !getenv("AA_UP_NO_NT")) ? 1 : 0;
+  p.store_nt = ((p.total_out_bytes > (64ull << 20) || getenv("AA_UP_FORCE_NT")) && !getenv("AA_UP_NO_NT")) ? 1 : 0;  // (FORCE: tests of the store forms at small sizes)
   // rows or planes that are not whole 64-byte sectors: stream only the whole sectors of each piece (see the store)
   if (p.store_nt && g.cpl == 4 && ((((uintptr_t)q.out) | (uint64_t)q.oW * 4u | p.plane_out_bytes) & 63u) != 0 && !getenv("AA_UP_NO_SPLIT"))
     p.store_nt = 2;
+  // ... and when the rows are 8-byte but not 16-byte aligned (oW = 906): strips cut at the sector boundaries of each row instead
+  // (see the store).  Measured, [256,3,196,320] gradients -> 438 x W (ms, split + pacing | sector-aligned pieces): W = 898 0.347 | 0.312,
+  // 906 0.321 | 0.301-0.311; rows that are 16-byte aligned are better off with the split: 900 0.257 | 0.303, 904 0.269 | 0.284
+  if (p.store_nt == 2 && q.oW % 4 == 2 && ((uintptr_t)q.out & 15) == 0 && !getenv("AA_UP_NO_ALN")) {
+    p.store_nt = 3;
+    p.strip_w = 240;
+    p.nstrips = (int)((q.oW + 14 + 239) / 240);
+    p.strips_per_block = p.nstrips <= 8 ? p.nstrips : 4;
+  }
   p.pace_all = getenv("AA_UP_PACE_ALL") ? 1 : 0;
   p.ybands = 1;
   p.n_groups = 0;
-  const size_t lds = (size_t)AA_UP_G * p.seg_bytes;
+  const size_t lds = (size_t)AA_UP_G * p.seg_bytes + (p.store_nt == 3 ? 1088 : 0);  // per strip: stage ring (+ the aligned-store staging area)
 
   int rc = 0;
 #define AA_UP_CASE(UU, CC) if (g.u == UU && g.cpl == CC) rc = launch_kr<UU, CC>(taps_h, p, q, lds)

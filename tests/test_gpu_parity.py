@@ -1045,3 +1045,39 @@ def test_u8_growing_heights_take_the_fused_gather_form(aa):
                 _lib.set_fused(1)
             assert va.endswith("_v3") and vb.startswith("generic"), (va, vb)
             assert torch.equal(a, b), (size, mode, va, vb)
+
+
+def test_backward_store_forms_agree(aa):
+    """The up-scaling / backward kernel stores large outputs with the streaming policy in three forms chosen from the row pitch:
+    whole pieces (rows of whole 64-byte sectors), pieces cut at each row's sector boundaries through an LDS shift (even widths),
+    and split policies with a pacing barrier (odd widths).  AA_UP_FORCE_NT applies them at test sizes: each must equal the generic
+    path bit for bit, for widths that end strips in every way (exactly full, two columns over, a short last strip)."""
+    import os
+    from interpolate_antialiasing_amd import _lib
+
+    torch.manual_seed(9)
+    os.environ["AA_UP_FORCE_NT"] = "1"
+    try:
+        for (h, w), (oh, ow) in (((196, 320), (438, 906)), ((50, 100), (131, 466)), ((50, 100), (77, 468)), ((40, 200), (90, 494)),
+                                 ((60, 90), (61, 258)), ((33, 300), (100, 905)), ((20, 128), (64, 512)), ((30, 400), (65, 1202))):
+            g = torch.randn(5, 3, h, w, device="cuda")
+            for fn in (aa.linear_backward, aa.cubic_backward):
+                _lib.set_fused(1)
+                a = fn(g, [h, w], [5, 3, oh, ow])
+                va = _lib.last_variant()
+                _lib.set_fused(0)
+                b = fn(g, [h, w], [5, 3, oh, ow])
+                _lib.set_fused(1)
+                assert va == "fused_f32_nchw_up", (va, (h, w), (oh, ow))
+                assert torch.equal(a, b), ((h, w), (oh, ow), fn.__name__)
+            x = torch.rand(3, 2, h, w, device="cuda") * 255 - 20  # forward up-scaling through the same kernel
+            _lib.set_fused(1)
+            a = aa.linear_forward(x, [oh, ow])
+            va = _lib.last_variant()
+            _lib.set_fused(0)
+            b = aa.linear_forward(x, [oh, ow])
+            _lib.set_fused(1)
+            assert va == "fused_f32_nchw_up" and torch.equal(a, b), (va, (h, w), (oh, ow))
+    finally:
+        _lib.set_fused(1)
+        del os.environ["AA_UP_FORCE_NT"]
