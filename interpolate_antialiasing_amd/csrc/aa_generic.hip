@@ -350,11 +350,11 @@ void launch_vpass(const TIn *mid, TOut *out, const char *table, int64_t planes, 
     return;
   }
   // 16 bytes of input per lane (4 floats; 16 bytes of a uint8 intermediate) when every row start is aligned for it and the rows
-  // are long enough to keep the lanes busy; then 4 elements per lane; otherwise one
+  // are long enough to keep the lanes busy; then 4 or 2 elements per lane; otherwise one
   auto fits = [&](int vw) {
     return rowlen % vw == 0 && rowlen >= 64 * vw && ((uintptr_t)mid % (vw * sizeof(TIn))) == 0 && ((uintptr_t)out % (vw * sizeof(TOut))) == 0;
   };
-  const int vw = (sizeof(TIn) == 1 && fits(16)) ? 16 : (fits(4) ? 4 : 1);
+  const int vw = (sizeof(TIn) == 1 && fits(16)) ? 16 : (fits(4) ? 4 : (fits(2) ? 2 : 1));
   const unsigned gx = (unsigned)((rowlen + 64 * vw - 1) / (64 * vw));
   const unsigned gy = grid_y_for((planes * oH + 3) / 4, gx);
   if (vw == 16) {
@@ -362,6 +362,8 @@ void launch_vpass(const TIn *mid, TOut *out, const char *table, int64_t planes, 
       hipLaunchKernelGGL((vpass_generic<Pipe, TIn, TOut, 16>), dim3(gx, gy), dim3(64, 4), 0, stream, mid, out, table, planes, H, oH, rowlen, ksize);
   } else if (vw == 4) {
     hipLaunchKernelGGL((vpass_generic<Pipe, TIn, TOut, 4>), dim3(gx, gy), dim3(64, 4), 0, stream, mid, out, table, planes, H, oH, rowlen, ksize);
+  } else if (vw == 2) {  // (906-wide rows: 2 mod 4; measured on the channels_last backward: 1.35 -> 1.0 ms)
+    hipLaunchKernelGGL((vpass_generic<Pipe, TIn, TOut, 2>), dim3(gx, gy), dim3(64, 4), 0, stream, mid, out, table, planes, H, oH, rowlen, ksize);
   } else {
     hipLaunchKernelGGL((vpass_generic<Pipe, TIn, TOut, 1>), dim3(gx, gy), dim3(64, 4), 0, stream, mid, out, table, planes, H, oH, rowlen, ksize);
   }

@@ -42,6 +42,12 @@ elif name == "planar":
 elif name == "bwd":
     x = torch.randn(256, 3, 196, 320, device=dev)
     fn = lambda: aa.linear_backward(x, [196, 320], [256, 3, 438, 906])
+elif name == "bwd_nhwc":
+    x = torch.randn(256, 3, 196, 320, device=dev).contiguous(memory_format=torch.channels_last)
+    fn = lambda: aa.linear_backward(x, [196, 320], [256, 3, 438, 906])
+elif name == "bwd_f64":
+    x = torch.randn(128, 3, 196, 320, device=dev, dtype=torch.float64)
+    fn = lambda: aa.linear_backward(x, [196, 320], [128, 3, 438, 906])
 elif name == "up":
     x = torch.rand(64, 3, 438, 906, device=dev) * 255
     fn = lambda: aa.linear_forward(x, [1200, 1200])
