@@ -226,6 +226,22 @@ def secondary_configs(dev):
     x1 = torch.randint(0, 256, (1, 438, 906, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
     add("configs[1] as written: uint8 channels_last [1,3,438,906]->[196,320] (latency)", lambda: aa.linear_forward(x1, [196, 320]),
         3 * (438 * 906 + 196 * 320))
+    try:  # cold call ("report cold first-call separately"): a shape never seen in this process — both weight tables are
+        # built on device (one 64-byte header read-back each), then the kernel runs; wall clock around call + synchronize
+        import time
+        colds = []
+        for k in range(5):
+            xc = torch.randint(0, 256, (1, 430 + k, 900 + k, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            aa.linear_forward(xc, [196, 320])
+            torch.cuda.synchronize()
+            colds.append((time.perf_counter() - t0) * 1e3)
+        res.append({"workload": "cold call: a new shape [1,3,430+k,900+k]->[196,320] uint8 channels_last, two device-side table builds + "
+                                "launch, wall clock incl. synchronize (median of 5 shapes)", "ms": round(sorted(colds)[2], 4),
+                    "variant": _lib.last_variant()})
+    except Exception as e:
+        res.append({"workload": "cold call (new shape)", "error": str(e)[:200]})
     try:  # the same B=1 call replayed from a HIP graph (what a latency-bound server would do)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
