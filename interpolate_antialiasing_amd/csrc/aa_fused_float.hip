@@ -337,7 +337,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   }
 }
 
-int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int64_t H, int64_t oH) {
+int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int taps_w, int64_t H, int64_t oH) {
   const int64_t max_yb = oH / 8 > 1 ? oH / 8 : 1;
   int64_t ybands = 1;
   double best = 1e30;
@@ -351,6 +351,11 @@ int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int64_t H, i
       ybands = yb;
     }
   }
+  // Narrow windows (bilinear-class shapes, memory-bound): twice the bands of the round model, while the launch is fewer than 8
+  // rounds — shorter work items even out the end of the kernel, and their extra halo rows cost little where the vector ALUs are
+  // half idle.  Measured (ms, model | doubled): [256,3,438,906] fp32 NCHW 0.287 | 0.271, channels_last 0.283 | 0.264, [64,3,1024,1024]
+  // fp16 bilinear 0.163 | 0.150; the 21-tap bicubic config (vector-ALU bound) loses with more bands (0.20 | 0.22) and keeps the model.
+  if (taps_w <= 12 && (double)items_per_band * ybands / slots < 8.0) ybands = 2 * ybands < max_yb ? 2 * ybands : max_yb;
   if (const char *e = getenv("AA_FUSED_YBANDS")) {
     const int64_t v = atoll(e);
     if (v >= 1 && v <= max_yb) ybands = v;
@@ -384,10 +389,14 @@ int launch_k(FusedF32Params p, const AAProblem &q) {
   const size_t lds_blk = lds * spb;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   const int64_t planes = CS == 1 ? q.N * q.C : q.N;
-  p.ybands = pick_ybands_f(planes * sgroups, (double)aa_device_cu_count() * resident(spb), taps_h, q.H, q.oH);
+  const int taps_w = q.aw.max_taps > 0 ? q.aw.max_taps : q.aw.ksize;
+  p.ybands = pick_ybands_f(planes * sgroups, (double)aa_device_cu_count() * resident(spb), taps_h, taps_w, q.H, q.oH);
   p.n_groups = planes * (int64_t)p.ybands;
   const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
+  if (getenv("AA_F32_DEBUG"))
+    fprintf(stderr, "f32: NQ=%d G=%d MAXC=%d DT=%d CS=%d nstrips=%d spb=%d resident=%d ybands=%d planes=%lld grid=%lld lds=%zu\n", NQ, G, MAXC, DT, CS,
+            p.nstrips, spb, resident(spb), p.ybands, (long long)planes, (long long)grid, lds_blk);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, q.in, q.out,
                      (const char *)q.aw.table_dev, (const char *)q.ah.table_dev, p);
   AA_HIP_CHECK_LAUNCH();
