@@ -59,6 +59,23 @@ __device__ inline void wait_vmcnt_f(int n) {  // rounding n DOWN only waits long
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#ifndef AA_F32_ANDMASK
+#define AA_F32_ANDMASK 0  // developer knob, kept off.  0: positions outside the lane's own taps are skipped with v_cndmask on the sum, lane
+                          // masks in scalar registers.  1: the (negated) product is AND-ed with a per-lane 0 / ~0 register and SUBTRACTED.
+#endif
+// skip a window position exactly: a - ((x * -w) & m).  m = ~0: a - (-(x w)) is a + x w bit for bit (IEEE subtraction is addition of
+// the negation); m = 0: whatever x * -w was (a non-finite neighbour included) becomes +0.0 and a - (+0.0) == a for EVERY a, -0.0 and
+// NaN included.  On gfx950 v_and_b32 and v_sub_f32 issue at the fast rate (3.3 cycles per wave), v_cndmask_b32 at 5.5
+// (profiles/r02_ubench_valu_issue_rates.txt): 9.9 instead of 12.2 issue cycles per position — but the masks then live in vector
+// registers (one per window position: 42 -> 54 registers for 12 positions, 79 -> 106 for 28) and the measured result, bit-identical,
+// is a wash: 21-tap bicubic 0.1995 -> 0.192 ms at its best band count, fp16 bilinear unchanged, config A fp32 0.254 -> 0.271 ms
+// (same box).  The select form stays.
+__device__ inline float sub_masked(float a, float negprod, unsigned m) { return a - __uint_as_float(__float_as_uint(negprod) & m); }
+__device__ inline double sub_masked(double a, double negprod, unsigned m) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(negprod);
+  const unsigned lo = (unsigned)u & m, hi = (unsigned)(u >> 32) & m;
+  return a - __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 // dst = mask[lane] ? b : a, the lane mask in a scalar register pair (no per-row compare)
 __device__ inline float select_by_mask(float a, float b, unsigned long long mask) {
   float d;
@@ -164,12 +181,16 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   const int tap0 = CS == 1 ? (start & (EPQ - 1)) + lead : lead;  // window position of the reference's tap 0
   real wreg[TWP];
   unsigned long long inwin[TWP];  // lane masks (scalar registers): position q belongs to the lane's own taps
+  unsigned mk[TWP];               // the same per lane: ~0 / 0
 #pragma unroll
   for (int q = 0; q < TWP; q++) {
     const int j = q - tap0;
     const bool mine = j >= 0 && j < xs;
     wreg[q] = (mine && j < p.ksize_w) ? kw[(size_t)ox * p.ksize_w + j] : (real)0;
     inwin[q] = __ballot(mine);
+    if (AA_F32_ANDMASK) wreg[q] = -wreg[q];  // (the product is subtracted, see sub_masked)
+    mk[q] = mine ? 0xFFFFFFFFu : 0u;
+    asm volatile("" : "+v"(mk[q]));  // (a plain register to the compiler: or it turns the AND back into a v_cndmask on a lane mask)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table loads done: from here on vmcnt counts DMAs and stores
   // lane 0 is always active and its PIXEL has the smallest window start (interleaved channels: take its channel 0, a
@@ -275,8 +296,12 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
       else if constexpr (DT == AA_F32) dq = __uint_as_float(d[q >> 2][q & 3]);
       else dq = elem_to_f32<DT>(d[q >> 3][(q >> 1) & 3] >> (16 * (q & 1)));
       const real prod = dq * wreg[q];
-      const real sum = acc + prod;
-      acc = select_by_mask(acc, sum, inwin[q]);
+      if constexpr (AA_F32_ANDMASK != 0) {
+        acc = sub_masked(acc, prod, mk[q]);
+      } else {
+        const real sum = acc + prod;
+        acc = select_by_mask(acc, sum, inwin[q]);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the window is in registers: the caller may refill the slot)
     const int cnt = sc.cc & 0xFFFF;
