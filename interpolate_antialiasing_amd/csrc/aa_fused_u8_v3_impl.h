@@ -351,10 +351,12 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     a = a < 0.f ? 0.f : (a > 255.f ? 255.f : a);
     return (unsigned)(int)a;
   };
+  // which store form the kernel uses is a launch constant: a scalar, so that the per-row choice is a scalar compare (as a bool
+  // merged across the branches below the compiler kept it in a lane mask: a v_cndmask + v_cmp per output row)
+  const int emit_path = __builtin_amdgcn_readfirstlane((FLT && p.outm != 0) ? 1 : (p.byte_store ? 2 : 0));
   auto emit = [&](int oy) {  // accumulator set 0 is complete: clip, pack, merge quads, store; then slide the sets down
-    bool stored = false;
     if constexpr (FLT) {
-      if (p.outm != 0) {  // (wave-uniform) float32 output: the accumulators themselves, one 256-byte row piece per plane
+      if (emit_path == 1) {  // (wave-uniform) float32 output: the accumulators themselves, one 256-byte row piece per plane
         float v[C];
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));  // (address arithmetic of this path stays inside it, see the byte-store path)
@@ -385,10 +387,9 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
             if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), orsrc, fv, fs, AA_V3_F32OUT_AUX);
           }
         }
-        stored = true;
       }
     }
-    if (!stored && p.byte_store) {  // (wave-uniform) ragged rows: C byte stores per lane
+    if (emit_path == 2) {  // (wave-uniform) ragged rows: C byte stores per lane
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));  // keep this rare path's address arithmetic INSIDE it: hoisted out of the row loop it
                                         // costs the common path 5 VGPRs, i.e. a wave per SIMD (76 -> 81 registers)
@@ -400,12 +401,11 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
         const unsigned b = FLT ? trunc8(A[0][c]) : (unsigned)clip8_int(A[0][c]);
         if (act) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, bv + c, (unsigned)oy * out_row_bytes, 0);
       }
-      stored = true;
     }
     if constexpr (UPK > 0) {
-      if (!stored) vm_issued += 1;  // the dword store below: lane 0 stores whenever the strip holds a whole quad (it does)
+      if (emit_path == 0) vm_issued += 1;  // the dword store below: lane 0 stores whenever the strip holds a whole quad (it does)
     }
-    if (stored) {
+    if (emit_path != 0) {
     } else if constexpr (C == 3) {
       const unsigned t = FLT ? (trunc8(A[0][0]) | (trunc8(A[0][1]) << 8) | (trunc8(A[0][2]) << 16))
                              : pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][2]);
