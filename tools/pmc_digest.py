@@ -52,6 +52,9 @@ if g("GRBM_GUI_ACTIVE") and g("SQ_ACTIVE_INST_VALU") is not None:
     # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; a SIMD issues one VALU instruction at a time, so over the chip's 1024
     # SIMDs and the kernel's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs) this is the share of time the vector ALUs were busy
     derived["valu_busy_share (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles))"] = round(g("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * g("GRBM_GUI_ACTIVE") / 8.0), 4)
+if g("GRBM_GUI_ACTIVE") and g("SQ_ACTIVE_INST_SCA") is not None:
+    # a SIMD issues at most one scalar (SALU / SMEM) instruction every 4 cycles (the CU's scalar unit serves its 4 SIMDs in turn)
+    derived["scalar_busy_share (SQ_ACTIVE_INST_SCA x 4 / (1024 SIMDs x cycles))"] = round(g("SQ_ACTIVE_INST_SCA") * 4.0 / (1024.0 * g("GRBM_GUI_ACTIVE") / 8.0), 4)
 if g("GRBM_GUI_ACTIVE") and g("SQ_LDS_IDX_ACTIVE") is not None:
     derived["lds_busy_share (SQ_LDS_IDX_ACTIVE / (256 CUs x cycles))"] = round(g("SQ_LDS_IDX_ACTIVE") / (256.0 * g("GRBM_GUI_ACTIVE") / 8.0), 4)
 out = {"workload_tag": tag, "kernel_substring": kern, "kernel_trace_stats": stats, "derived": derived}
