@@ -71,7 +71,7 @@ __global__ void k_dma_align(const uint8_t *src, unsigned bytes, int delta, int s
 }
 
 static void part2() {
-  const unsigned bytes = 1 << 16;
+  const unsigned bytes = 1 << 20;
   std::vector<uint8_t> h(bytes);
   for (unsigned i = 0; i < bytes; i++) h[i] = (uint8_t)((i * 2654435761u) >> 13);
   uint8_t *src, *out;
@@ -440,11 +440,86 @@ static void part4() {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------- part 5
+// issue interval of the matrix instructions themselves: NACC independent accumulators, operands in registers
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int KIND>
+__global__ void __launch_bounds__(256) k_mfma_rate(int iters, unsigned *out, unsigned long long *cyc) {
+  const int lane = threadIdx.x & 63;
+  v4i a = {lane, lane * 3, lane * 5, lane * 7}, b = {lane * 11, lane * 13, lane * 17, lane * 19};
+  unsigned chk = 0;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  if (KIND == 0) {
+    v4i acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = v4i{0, 0, 0, 0};
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 8; i++) chk ^= (unsigned)(acc[i].x ^ acc[i].y ^ acc[i].z ^ acc[i].w);
+  } else if (KIND == 1) {
+    v16i acc[4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 16; j++) acc[i][j] = 0;
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 16; j++) chk ^= (unsigned)acc[i][j];
+  } else {
+    v4f acc[8];
+    v8s ha, hb;
+    for (int j = 0; j < 8; j++) { ha[j] = (short)(0x3f80 + lane + j); hb[j] = (short)(0x3f80 + lane * 3 + j); }
+    for (int i = 0; i < 8; i++) acc[i] = v4f{0, 0, 0, 0};
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb, acc[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 8; i++) chk ^= __float_as_uint(acc[i].x + acc[i].y + acc[i].z + acc[i].w);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (chk == 0x12345678u) out[0] = chk;
+  if (lane == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+static void part5() {
+  unsigned *out; unsigned long long *cyc;
+  CK(hipMalloc(&out, 64)); CK(hipMalloc(&cyc, 256 * 16 * 8));
+  const int iters = 20000;
+  for (int kind = 0; kind < 3; kind++)
+    for (int wps = 1; wps <= 2; wps++) {
+      const int waves = 4 * wps, per_iter = kind == 1 ? 4 : 8;
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      float ms = 0;
+      for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(e0);
+        if (kind == 0) hipLaunchKernelGGL(k_mfma_rate<0>, dim3(256), dim3(64 * waves), 0, 0, iters, out, cyc);
+        else if (kind == 1) hipLaunchKernelGGL(k_mfma_rate<1>, dim3(256), dim3(64 * waves), 0, 0, iters, out, cyc);
+        else hipLaunchKernelGGL(k_mfma_rate<2>, dim3(256), dim3(64 * waves), 0, 0, iters, out, cyc);
+        hipEventRecord(e1); CK(hipEventSynchronize(e1));
+        hipEventElapsedTime(&ms, e0, e1);
+      }
+      std::vector<unsigned long long> c((size_t)256 * waves);
+      CK(hipMemcpy(c.data(), cyc, c.size() * 8, hipMemcpyDeviceToHost));
+      double s = 0; for (auto v : c) s += (double)v;
+      const double ticks = s / c.size() / ((double)iters * per_iter);
+      printf("part5 %-28s waves/SIMD %d: %.1f ticks per instruction and wave = %.1f per SIMD; %.2f ns per instruction and SIMD (clock %.2f GHz)\n",
+             kind == 0 ? "v_mfma_i32_16x16x64_i8" : (kind == 1 ? "v_mfma_i32_32x32x32_i8" : "v_mfma_f32_16x16x32_bf16"), wps, ticks, ticks / wps,
+             ms * 1e6 / ((double)iters * per_iter * wps), ticks / wps / (ms * 1e6 / ((double)iters * per_iter * wps)));
+    }
+}
+
 int main(int argc, char **argv) {
   const int only = argc > 1 ? atoi(argv[1]) : 0;
   if (only == 0 || only == 1) part1();
   if (only == 0 || only == 2) part2();
   if (only == 0 || only == 3) part3();
   if (only == 0 || only == 4) part4();
+  if (only == 0 || only == 5) part5();
   return 0;
 }
