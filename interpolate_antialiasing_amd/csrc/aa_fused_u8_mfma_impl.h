@@ -42,6 +42,12 @@
 #ifndef AA_MFMA_ABL
 #define AA_MFMA_ABL 0
 #endif
+#ifndef AA_MFMA_NOSYNC
+#define AA_MFMA_NOSYNC 0  // developer knob (wrong results!): 1 = no barriers and no vmcnt waits in the block loop
+#endif
+#ifndef AA_MFMA_LOADERS
+#define AA_MFMA_LOADERS 3  // developer knob: waves 0 .. LOADERS-1 issue the row DMAs
+#endif
 #ifndef AA_MFMA_DMA_MASK
 #define AA_MFMA_DMA_MASK 0  // developer knob (wrong results!): low bits cleared from every row DMA's source address
 #endif
@@ -389,10 +395,10 @@ __global__ void __launch_bounds__(256) fused_u8_nhwc_mfma_kernel(const FusedU8Mf
   int markw[2] = {0, 0};  // wave 3: `issued` right after the DMAs of the Bv operands in buffer 0 / 1
 
   auto dma_block = [&](int x, int slot) {  // this wave's share of block x (rows 16 x .. 16 x + 15) into ring slot `slot`
-    if (AA_MFMA_ABL != 4 && wv < 3) {
+    if (AA_MFMA_ABL != 4 && wv < AA_MFMA_LOADERS) {
       uint8_t *dst = lds + slot * blk_bytes;
       const unsigned arow = a_img + (unsigned)(16 * (AA_MFMA_SKEL == 7 ? (x & 1) : x)) * row_bytes;
-      for (int m = wv * rpi; m < 16; m += 3 * rpi) {  // rows m .. m + rpi - 1 (lane 0 always takes part: the instruction is certainly issued)
+      for (int m = wv * rpi; m < 16; m += AA_MFMA_LOADERS * rpi) {  // rows m .. m + rpi - 1 (lane 0 always takes part: the instruction is certainly issued)
         const int nr = 16 - m < rpi ? 16 - m : rpi;
         if (lrow < nr) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + m * row_pitch), 16, voff, (arow + (unsigned)m * row_bytes) & ~(unsigned)AA_MFMA_DMA_MASK, 0, 0);
         issued++;
@@ -467,8 +473,8 @@ __global__ void __launch_bounds__(256) fused_u8_nhwc_mfma_kernel(const FusedU8Mf
             allow = aw2 < allow ? aw2 : allow;
           }
         }
-        wait_vmcnt_le(allow);
-        if (AA_MFMA_SKEL != 6) __builtin_amdgcn_s_barrier();
+        if (!AA_MFMA_NOSYNC) wait_vmcnt_le(allow);
+        if (AA_MFMA_SKEL != 6 && !AA_MFMA_NOSYNC) __builtin_amdgcn_s_barrier();
         // every wave has finished block x - 1 and the vertical pass behind it: its ring slot is free, output tiles written there
         // are complete, and the Bv buffer of tile jt - 1 is free
         {

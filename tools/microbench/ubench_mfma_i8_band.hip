@@ -442,48 +442,35 @@ static void part4() {
 
 
 // ------------------------------------------------------------------------------------------------------------- part 5
-// issue interval of the matrix instructions themselves: NACC independent accumulators, operands in registers
-typedef int v16i __attribute__((ext_vector_type(16)));
-typedef short v8s __attribute__((ext_vector_type(8)));
-typedef float v4f __attribute__((ext_vector_type(4)));
+// issue interval of the matrix instructions themselves: 8 independent accumulators, operands in registers, inline asm (hipcc's own
+// code for an accumulator array in a loop shuffles everything through AGPRs)
 template <int KIND>
-__global__ void __launch_bounds__(256) k_mfma_rate(int iters, unsigned *out, unsigned long long *cyc) {
+__global__ void __launch_bounds__(512) k_mfma_rate(int iters, unsigned *out, unsigned long long *cyc) {
   const int lane = threadIdx.x & 63;
   v4i a = {lane, lane * 3, lane * 5, lane * 7}, b = {lane * 11, lane * 13, lane * 17, lane * 19};
-  unsigned chk = 0;
+  v4i c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
   const unsigned long long t0 = __builtin_readcyclecounter();
-  if (KIND == 0) {
-    v4i acc[8];
-    for (int i = 0; i < 8; i++) acc[i] = v4i{0, 0, 0, 0};
 #pragma unroll 1
-    for (int it = 0; it < iters; it++) {
-#pragma unroll
-      for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[i], 0, 0, 0);
-    }
-    for (int i = 0; i < 8; i++) chk ^= (unsigned)(acc[i].x ^ acc[i].y ^ acc[i].z ^ acc[i].w);
-  } else if (KIND == 1) {
-    v16i acc[4];
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 16; j++) acc[i][j] = 0;
-#pragma unroll 1
-    for (int it = 0; it < iters; it++) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[i], 0, 0, 0);
-    }
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 16; j++) chk ^= (unsigned)acc[i][j];
-  } else {
-    v4f acc[8];
-    v8s ha, hb;
-    for (int j = 0; j < 8; j++) { ha[j] = (short)(0x3f80 + lane + j); hb[j] = (short)(0x3f80 + lane * 3 + j); }
-    for (int i = 0; i < 8; i++) acc[i] = v4f{0, 0, 0, 0};
-#pragma unroll 1
-    for (int it = 0; it < iters; it++) {
-#pragma unroll
-      for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb, acc[i], 0, 0, 0);
-    }
-    for (int i = 0; i < 8; i++) chk ^= __float_as_uint(acc[i].x + acc[i].y + acc[i].z + acc[i].w);
+  for (int it = 0; it < iters; it++) {
+    if (KIND == 0)
+      asm volatile(
+          "v_mfma_i32_16x16x64_i8 %0, %8, %9, %0\n\tv_mfma_i32_16x16x64_i8 %1, %8, %9, %1\n\tv_mfma_i32_16x16x64_i8 %2, %8, %9, %2\n\t"
+          "v_mfma_i32_16x16x64_i8 %3, %8, %9, %3\n\tv_mfma_i32_16x16x64_i8 %4, %8, %9, %4\n\tv_mfma_i32_16x16x64_i8 %5, %8, %9, %5\n\t"
+          "v_mfma_i32_16x16x64_i8 %6, %8, %9, %6\n\tv_mfma_i32_16x16x64_i8 %7, %8, %9, %7"
+          : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+          : "v"(a), "v"(b));
+    else
+      asm volatile(
+          "v_mfma_f32_16x16x32_bf16 %0, %8, %9, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %8, %9, %1\n\tv_mfma_f32_16x16x32_bf16 %2, %8, %9, %2\n\t"
+          "v_mfma_f32_16x16x32_bf16 %3, %8, %9, %3\n\tv_mfma_f32_16x16x32_bf16 %4, %8, %9, %4\n\tv_mfma_f32_16x16x32_bf16 %5, %8, %9, %5\n\t"
+          "v_mfma_f32_16x16x32_bf16 %6, %8, %9, %6\n\tv_mfma_f32_16x16x32_bf16 %7, %8, %9, %7"
+          : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+          : "v"(a), "v"(b));
   }
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
   const unsigned long long t1 = __builtin_readcyclecounter();
-  if (chk == 0x12345678u) out[0] = chk;
+  const v4i s = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+  if ((unsigned)(s.x ^ s.y ^ s.z ^ s.w) == 0x12345678u) out[0] = 1;
   if (lane == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
@@ -491,26 +478,25 @@ static void part5() {
   unsigned *out; unsigned long long *cyc;
   CK(hipMalloc(&out, 64)); CK(hipMalloc(&cyc, 256 * 16 * 8));
   const int iters = 20000;
-  for (int kind = 0; kind < 3; kind++)
+  for (int kind = 0; kind < 2; kind++)
     for (int wps = 1; wps <= 2; wps++) {
-      const int waves = 4 * wps, per_iter = kind == 1 ? 4 : 8;
+      const int waves = 4 * wps;
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       float ms = 0;
       for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(e0);
         if (kind == 0) hipLaunchKernelGGL(k_mfma_rate<0>, dim3(256), dim3(64 * waves), 0, 0, iters, out, cyc);
-        else if (kind == 1) hipLaunchKernelGGL(k_mfma_rate<1>, dim3(256), dim3(64 * waves), 0, 0, iters, out, cyc);
-        else hipLaunchKernelGGL(k_mfma_rate<2>, dim3(256), dim3(64 * waves), 0, 0, iters, out, cyc);
+        else hipLaunchKernelGGL(k_mfma_rate<1>, dim3(256), dim3(64 * waves), 0, 0, iters, out, cyc);
         hipEventRecord(e1); CK(hipEventSynchronize(e1));
         hipEventElapsedTime(&ms, e0, e1);
       }
       std::vector<unsigned long long> c((size_t)256 * waves);
       CK(hipMemcpy(c.data(), cyc, c.size() * 8, hipMemcpyDeviceToHost));
       double s = 0; for (auto v : c) s += (double)v;
-      const double ticks = s / c.size() / ((double)iters * per_iter);
-      printf("part5 %-28s waves/SIMD %d: %.1f ticks per instruction and wave = %.1f per SIMD; %.2f ns per instruction and SIMD (clock %.2f GHz)\n",
-             kind == 0 ? "v_mfma_i32_16x16x64_i8" : (kind == 1 ? "v_mfma_i32_32x32x32_i8" : "v_mfma_f32_16x16x32_bf16"), wps, ticks, ticks / wps,
-             ms * 1e6 / ((double)iters * per_iter * wps), ticks / wps / (ms * 1e6 / ((double)iters * per_iter * wps)));
+      const double ticks = s / c.size() / ((double)iters * 8);
+      const double ns = ms * 1e6 / ((double)iters * 8 * wps);
+      printf("part5 %-26s waves/SIMD %d: %.1f ticks per instruction and wave = %.1f per SIMD; %.2f ns per instruction and SIMD (clock %.2f GHz)\n",
+             kind == 0 ? "v_mfma_i32_16x16x64_i8" : "v_mfma_f32_16x16x32_bf16", wps, ticks, ticks / wps, ns, ticks / wps / ns);
     }
 }
 
