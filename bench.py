@@ -32,7 +32,7 @@ H_IN, W_IN, H_OUT, W_OUT, CH = 438, 906, 196, 320, 3
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, which also quotes a 6.29 TB/s float4-copy ceiling)
 GUIDE_COPY_CEILING_GBS = 6290.0
 PMC_SUMMARIES = {  # dominant kernel -> committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes), newest first
-    "fused_u8_nhwc_pil_v3": ("r02_pmc_fused_v3.json", "r01_pmc_fused_v3.json"),
+    "fused_u8_nhwc_pil_v3": ("r03_pmc_fused_v3.json", "r02_pmc_fused_v3.json", "r01_pmc_fused_v3.json"),
     "fused_u8_nhwc_pil": ("r01_pmc_fused_v1.json",),
 }
 
@@ -43,7 +43,12 @@ def pmc_traffic_bytes(variant: str, batch: int):
     from MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 128-byte requests of a 16-B-per-lane stream as 64 B -> x2; WRITE_SIZE is
     exact.  The counters cannot be read from inside a process (they need rocprofv3 around it), so this is NOT live: the source
     file is named in the bench line, and traffic scales with the batch (every image is fetched and written exactly once).
-    (None, None) when no summary matches the kernel that ran."""
+    Third value: True when the summary is STALE — it carries the fingerprint of the kernel's sources at profiling time
+    (tools/pmc_digest.py stamps it) and the sources have changed since, or it carries none; False when they match.
+    (None, None, None) when no summary matches the kernel that ran."""
+    from interpolate_antialiasing_amd import _lib
+
+    now = _lib.source_fingerprint(variant)
     for name in PMC_SUMMARIES.get(variant, ()):
         path = os.path.join(ROOT, "profiles", name)
         try:
@@ -54,8 +59,10 @@ def pmc_traffic_bytes(variant: str, batch: int):
             pmc_batch = int(d.get("batch", 1024))
         except (OSError, KeyError, ValueError):
             continue
-        return int((2.0 * fetch + write) * 1024 * batch / pmc_batch), f"profiles/{name} (batch {pmc_batch})"
-    return None, None
+        stamped = d.get("source_fingerprint")
+        stale = stamped is None or now is None or stamped != now
+        return int((2.0 * fetch + write) * 1024 * batch / pmc_batch), f"profiles/{name} (batch {pmc_batch}, sources {stamped})", stale
+    return None, None, None
 
 
 def measure_copy_ceiling(dev, nbytes=2 << 30, reps=10):
@@ -183,7 +190,8 @@ def secondary_configs(dev):
     def add(name, fn, nbytes):
         try:
             ms = timed(fn)
-            res.append({"workload": name, "ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "variant": _lib.last_variant()})
+            res.append({"workload": name, "ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1),
+                        "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "variant": _lib.last_variant()})
         except Exception as e:  # a secondary line must never take the headline down with it
             res.append({"workload": name, "error": str(e)[:200]})
         torch.cuda.empty_cache()
@@ -275,6 +283,11 @@ def parse_args(argv=None):
                     help="exercise the rank launcher only: every rank prints its rendezvous environment and exits before any "
                          "GPU call; rank 0 also prints the bench line's skeleton (n_gpus, global_batch).  Runs without a GPU.")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0 = pick a free one)")
+    ap.add_argument("--force-launcher", action="store_true",
+                    help="take the self-launching path even with --gpus 1: the parent starts ONE fresh rank process, which joins a "
+                         "1-rank RCCL process group (init_process_group, table broadcast, barriers, reductions all run).  This is how the "
+                         "multi-rank code path is exercised end to end on a one-GPU box.")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0, help="launcher: seconds before the ranks are killed")
     return ap.parse_args(argv)
 
 
@@ -291,20 +304,56 @@ def launch_ranks(args, argv):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
-    procs = []
+    import tempfile
+    import threading
+
+    procs, errfiles = [], []
     for rank in range(args.gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE, stderr=None if rank == 0 else subprocess.PIPE, text=True))
-    rc = 0
-    outs = []
-    for rank, p in enumerate(procs):
-        out, err = p.communicate()
-        outs.append(out)
-        if p.returncode != 0:
-            rc = rc or p.returncode or 1
-            sys.stderr.write(f"[bench launcher] rank {rank} exited with {p.returncode}\n{(err or '')[-2000:]}\n")
+        if args.force_launcher:
+            env["AA_BENCH_FORCE_DIST"] = "1"
+        # stderr of ranks > 0 goes to a temporary FILE (a chatty rank — RCCL debug output, a traceback storm — can then never block
+        # on a full pipe while rank 0 waits for it in a collective); every rank's stdout is drained by its own thread
+        ef = None if rank == 0 else tempfile.TemporaryFile(mode="w+")
+        errfiles.append(ef)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--force-launcher"], env=env,
+                                      stdout=subprocess.PIPE, stderr=ef, text=True))
+    outs = [""] * len(procs)
+
+    def drain(i):
+        outs[i] = procs[i].stdout.read()
+
+    threads = [threading.Thread(target=drain, args=(i,), daemon=True) for i in range(len(procs))]
+    for t in threads:
+        t.start()
+    deadline = time.time() + args.rank_timeout
+    rc, failed = 0, None
+    while True:  # poll all ranks: when one fails (or time runs out) the others are killed instead of waiting in a collective for ever
+        states = [p.poll() for p in procs]
+        bad = [i for i, st in enumerate(states) if st not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = bad[0] if bad else -1
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        if all(st == 0 for st in states):
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    for t in threads:
+        t.join(timeout=5)
+    if failed is not None:
+        rc = 1
+        for rank, p in enumerate(procs):
+            err = ""
+            if errfiles[rank] is not None:
+                errfiles[rank].seek(0)
+                err = errfiles[rank].read()
+            sys.stderr.write(f"[bench launcher] rank {rank} exited with {p.returncode}" + (" (first failure)" if rank == failed else "")
+                             + (" [timeout]" if failed == -1 else "") + f"\n{err[-2000:]}\n")
     if args.launch_dry_run:  # every rank's environment line, rank order
         for out in outs:
             sys.stdout.write(out)
@@ -319,7 +368,7 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_launcher):
         raise SystemExit(launch_ranks(args, argv))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -332,6 +381,14 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.launch_dry_run:  # before any GPU call
+        hook = os.environ.get("AA_BENCH_DRYRUN_HOOK", "")  # launcher tests: "chatty" = every rank > 0 writes 1 MB to stderr first;
+        if hook == "chatty" and rank > 0:                  # "fail1" = rank 1 exits non-zero while rank 0 would wait for ever
+            sys.stderr.write("x" * (1 << 20))
+            sys.stderr.flush()
+        if hook == "fail1":
+            if rank == 1:
+                raise SystemExit(3)
+            time.sleep(600)
         line = {"dry_run": True, "rank": rank, "local_rank": local_rank, "world": world,
                 "master": f"{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '')}"}
         if rank == 0:
@@ -342,7 +399,9 @@ def main(argv=None):
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # (AA_BENCH_FORCE_DIST: set by --force-launcher for its one rank, so that a 1-rank RCCL group runs the whole multi-rank path)
+    use_dist = world > 1 or os.environ.get("AA_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from interpolate_antialiasing_amd import _lib, sharding
@@ -370,7 +429,7 @@ def main(argv=None):
         y = step()
     variant = _lib.last_variant()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -381,7 +440,7 @@ def main(argv=None):
         y = step()
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -401,7 +460,8 @@ def main(argv=None):
         alg_bytes_img = CH * H_IN * W_IN + CH * H_OUT * W_OUT  # 1,378,644
         kern_ms = ev_ms / args.steps  # one hot-path pass per step
         achieved = alg_bytes_img * B / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic_bytes(variant, B)
+        traffic, traffic_src, traffic_stale = pmc_traffic_bytes(variant, B)
+        in_bytes_img = CH * H_IN * W_IN
         del y
         ceiling, ceiling_forms = measure_copy_ceiling(dev) if world == 1 else (None, {})  # (after the timed region; N = 1 only)
         out = {
@@ -412,23 +472,31 @@ def main(argv=None):
             "config": {"workload": f"uint8 channels_last [{B},3,438,906]->[196,320] bilinear antialias per GPU "
                                    f"(BASELINE configs[1] batched), Pillow-exact integer arithmetic",
                        "batch_per_gpu": B, "global_batch": B * world, "variant": variant, "prewarm_s": args.prewarm_seconds,
-                       "parallelism": f"batch-shard x{world}"},
+                       "parallelism": f"batch-shard x{world}", "lib": os.path.relpath(_lib.LIB_PATH, ROOT),
+                       "kernel_sources": _lib.source_fingerprint(variant), "process_group": "nccl" if use_dist else None},
             "max_abs_err_vs_oracle": max_abs_e,
             "images_per_s": round(total_images / wall, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # north_star's wording is the HBM-READ roofline: input bytes only
+                         "read_frac": round(in_bytes_img * B / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "kernel": variant, "kernel_ms": round(kern_ms, 4), "alg_bytes_per_launch": alg_bytes_img * B,
                          "copy_ceiling_measured_GBs": None if ceiling is None else round(ceiling, 1),
                          "copy_ceiling_by_kernel_form": ceiling_forms,
                          "frac_of_measured_copy_ceiling": None if ceiling is None else round(achieved / ceiling, 4),
                          "frac_of_guide_copy_ceiling_6290": round(achieved / GUIDE_COPY_CEILING_GBS, 4)},
         }
-        if world == 1 and not args.no_secondary:
-            out["secondary"] = secondary_configs(dev)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        # secondary workloads, the copy ceiling and the CPU baseline are rank-0-at-N=1 measurements (the contract): an N > 1 line says
+        # so explicitly instead of dropping the keys
+        if world > 1:
+            out["secondary"], out["cpu_baseline"] = None, None
+            out["n1_only"] = "secondary, cpu_baseline and the copy ceiling are measured at --gpus 1 only"
+        else:
+            out["secondary"] = None if args.no_secondary else secondary_configs(dev)
+            out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -145,3 +145,25 @@ def set_fused(enabled: int) -> int:
 
 def last_variant() -> str:
     return load().aa_last_variant().decode()
+
+
+# sources a kernel variant is compiled from (csrc/): profiles/*.json summaries are stamped with their fingerprint, and bench.py
+# flags a committed counter summary as stale when the sources of the kernel it describes have changed since
+KERNEL_SOURCES = {
+    "fused_u8_nhwc_pil_v3": ("aa_fused_u8_v3_impl.h", "aa_fused_u8_v3.hip", "aa_fused_u8_v3_c3.hip", "aa_common.h"),
+    "fused_u8_nhwc_pil": ("aa_fused_u8.hip", "aa_common.h"),
+}
+
+
+def source_fingerprint(variant: str):
+    """sha256[:12] over the source files of `variant` (None for a variant without an entry in KERNEL_SOURCES)."""
+    import hashlib
+
+    names = KERNEL_SOURCES.get(variant)
+    if not names:
+        return None
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(_HERE, "csrc", n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()[:12]

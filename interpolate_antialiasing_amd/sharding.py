@@ -17,6 +17,14 @@ from . import tables
 from .tables import META_LEN, WeightTable
 
 
+def _collectives_at_world_one() -> bool:
+    """A 1-rank process group normally skips its (no-op) collectives.  bench.py --force-launcher sets AA_BENCH_FORCE_DIST=1 so
+    that they run anyway: the only way to push the RCCL code path through real hardware on a one-GPU box."""
+    import os
+
+    return os.environ.get("AA_BENCH_FORCE_DIST") == "1"
+
+
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [start, stop) of ``total`` units for ``rank``; remainders go to the lowest ranks; a rank may
     get an empty range when total < world."""
@@ -69,7 +77,7 @@ def prepare_tables(filter_id: int, kind: int, in_hw: Tuple[int, int], out_hw: Tu
     out: List[WeightTable] = []
     for n_in, n_out in ((in_hw[0], out_hw[0]), (in_hw[1], out_hw[1])):
         t = tables.get_table(filter_id, kind, n_in, n_out, align_corners, 0.0, device) if rank == src else None
-        if world > 1:
+        if world > 1 or (dist.is_initialized() and _collectives_at_world_one()):
             t = broadcast_table(t, src=src, device=device, group=group)
             if rank != src:
                 tables.put_table(t)
@@ -79,7 +87,7 @@ def prepare_tables(filter_id: int, kind: int, in_hw: Tuple[int, int], out_hw: Tu
 
 def reduce_max_seconds(seconds: float, device: Optional[torch.device] = None, group=None) -> float:
     """MAX over ranks of a timing (bench.py contract)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _collectives_at_world_one()):
         return seconds
     backend = dist.get_backend(group)
     dev = torch.device(device) if backend == "nccl" else torch.device("cpu")
@@ -89,7 +97,7 @@ def reduce_max_seconds(seconds: float, device: Optional[torch.device] = None, gr
 
 
 def reduce_sum_int(value: int, device: Optional[torch.device] = None, group=None) -> int:
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _collectives_at_world_one()):
         return value
     backend = dist.get_backend(group)
     dev = torch.device(device) if backend == "nccl" else torch.device("cpu")

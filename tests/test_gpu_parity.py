@@ -5,11 +5,16 @@ Bars: bit-exact for uint8 (Pillow semantics and harness semantics) and for the w
 forward is ALSO held bit-exact against the reference build's outputs (the kernels round product and sum
 separately, in tap order, like the reference's CPU code) — the north-star tolerance is 1e-4 relative.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -1081,3 +1086,22 @@ def test_backward_store_forms_agree(aa):
     finally:
         _lib.set_fused(1)
         del os.environ["AA_UP_FORCE_NT"]
+
+
+@pytest.mark.gpu
+def test_bench_rank_path_through_the_launcher():
+    """The multi-rank code path end to end on hardware, as a fresh process: `bench.py --gpus 1 --force-launcher` makes the parent
+    (which never touches the GPU) start one rank that joins a 1-rank RCCL process group, receives the tables by broadcast, runs the
+    timed loop between barriers and reduces its timing — everything an N-GPU run does except a second rank."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-launcher", "--batch", "8", "--steps", "3",
+                          "--warmup", "1", "--prewarm-seconds", "0", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["process_group"] == "nccl" and line["max_abs_err_vs_oracle"] == 0
+    assert line["value"] > 0 and line["secondary"] is None and line["cpu_baseline"] is None
+    assert line["roofline"]["read_frac"] < line["roofline"]["frac"]

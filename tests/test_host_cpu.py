@@ -218,6 +218,24 @@ def test_bench_launcher_starts_n_ranks():
     assert out.returncode != 0 and "torch.distributed.run" in out.stderr
 
 
+def test_bench_launcher_survives_chatty_and_failing_ranks():
+    """The launcher drains every rank concurrently (stderr of ranks > 0 into files, stdout by threads) and polls all of them:
+    a rank that writes a megabyte to stderr cannot block on a pipe, and when one rank fails the others are killed instead of
+    waiting in a collective until the driver's timeout (round-2 advisor finding on launch_ranks)."""
+    import json
+    import time
+
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-dry-run"], capture_output=True, text=True,
+                         timeout=300, env=dict(base, AA_BENCH_DRYRUN_HOOK="chatty"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert [json.loads(l)["rank"] for l in out.stdout.splitlines() if l.startswith("{")] == [0, 1, 2]
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-dry-run"], capture_output=True, text=True,
+                         timeout=300, env=dict(base, AA_BENCH_DRYRUN_HOOK="fail1"))
+    assert out.returncode != 0 and "rank 1 exited with 3" in out.stderr and time.time() - t0 < 120, (out.returncode, out.stderr[-500:])
+
+
 def test_headline_kernel_keeps_six_waves_per_simd(tmp_path):
     """Occupancy regression guard (no GPU needed: read from the built code object).  The headline kernel — uint8 channels_last,
     3 channels, 6-tap windows, 2 open output rows, non-negative weights, periodic slot phases — must stay within 80 VGPRs
