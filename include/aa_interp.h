@@ -218,6 +218,12 @@ int aa_probe_copy(const void *src_dev, void *dst_dev, size_t bytes, int form, aa
  * independent implementation at sizes the CPU oracle cannot reach, and by bench.py for A/B numbers. */
 int aa_set_fused(int enabled);
 
+/* Store form of the up-scaling / backward kernel, process-wide; returns the previous setting.  -1 (default): chosen from the output
+ * size (outputs beyond 64 MiB are stored with the streaming policy, in one of three forms picked from the row pitch); 1: always the
+ * streaming forms; 0: never.  A test hook: it lets the parity tests reach the streaming forms at sizes the CPU oracle can check.
+ * The library reads NO environment variables (developer builds with -DAA_V2_TUNING do, for experiments). */
+int aa_set_store_form(int form);
+
 /* Name of the kernel variant the last aa_resample_fwd on this thread dispatched to (for tests/bench). */
 const char *aa_last_variant(void);
 

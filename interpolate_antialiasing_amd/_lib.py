@@ -27,7 +27,7 @@ EXPORTS = (
     "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build_bytes", "aa_table_build",
     "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_workspace_bytes", "aa_resample_fwd",
     "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_resample_axis_fwd", "aa_set_fused",
-    "aa_last_variant", "aa_probe_copy", "aa_workspace_bytes_u8_to_f32", "aa_resample_fwd_u8_to_f32",
+    "aa_last_variant", "aa_probe_copy", "aa_workspace_bytes_u8_to_f32", "aa_resample_fwd_u8_to_f32", "aa_set_store_form",
 )
 
 
@@ -115,6 +115,8 @@ def load() -> ctypes.CDLL:
     L.aa_probe_copy.restype = i32
     L.aa_set_fused.argtypes = [i32]
     L.aa_set_fused.restype = i32
+    L.aa_set_store_form.argtypes = [i32]
+    L.aa_set_store_form.restype = i32
     if L.aa_abi_version() != 2:
         raise AAInterpError("libaa_interp.so ABI version mismatch")
     _lib = L
@@ -141,6 +143,11 @@ def set_fused(enabled: int) -> int:
     global fused_epoch
     fused_epoch += 1
     return int(load().aa_set_fused(int(enabled)))
+
+
+def set_store_form(form: int) -> int:
+    """Test hook: -1 automatic, 0 never / 1 always the streaming store forms of the up-scaling / backward kernel; returns the previous setting."""
+    return int(load().aa_set_store_form(int(form)))
 
 
 def last_variant() -> str:

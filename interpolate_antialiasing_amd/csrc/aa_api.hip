@@ -6,6 +6,8 @@
 
 #include "aa_common.h"
 
+int g_aa_store_form = -1;  // (aa_common.h; read by aa_fused_float_up.hip)
+
 namespace {
 
 thread_local const char *g_last_variant = "none";
@@ -381,6 +383,12 @@ int aa_set_fused(int enabled) {
   const int prev = g_fused_enabled;
   // 0 generic two-pass, 1 auto (newest fused design first), 2 first-generation fused kernels only
   g_fused_enabled = (enabled < 0 || enabled > 2) ? 1 : enabled;
+  return prev;
+}
+
+int aa_set_store_form(int form) {
+  const int prev = g_aa_store_form;
+  g_aa_store_form = (form < -1 || form > 1) ? -1 : form;
   return prev;
 }
 

@@ -47,6 +47,19 @@ __host__ __device__ inline TableView<WT> make_table_view(const void *table, int 
   return v;
 }
 
+// ---- experiment knobs ------------------------------------------------------------------------------------------------
+// Environment variables are read by developer builds only (make TUNING=-DAA_V2_TUNING, tools/ab_build.sh): the shipped library
+// never calls getenv, so its behaviour cannot depend on the ambient environment and a B = 1 call pays no lookups.
+#include <stdlib.h>
+#ifdef AA_V2_TUNING
+inline const char *aa_knob(const char *name) { return getenv(name); }
+#else
+inline const char *aa_knob(const char *) { return nullptr; }
+#endif
+// store form of the up-scaling / backward kernel, set through aa_set_store_form() (tests force the streaming forms at small sizes):
+// -1 automatic (by output size), 0 never streaming, 1 always streaming
+extern int g_aa_store_form;
+
 // ---- launch-error plumbing -------------------------------------------------------------------------------
 #define AA_HIP_CHECK_LAUNCH()                 \
   do {                                        \

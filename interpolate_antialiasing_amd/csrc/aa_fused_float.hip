@@ -381,7 +381,7 @@ int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int taps_w, 
   // half idle.  Measured (ms, model | doubled): [256,3,438,906] fp32 NCHW 0.287 | 0.271, channels_last 0.283 | 0.264, [64,3,1024,1024]
   // fp16 bilinear 0.163 | 0.150; the 21-tap bicubic config (vector-ALU bound) loses with more bands (0.20 | 0.22) and keeps the model.
   if (taps_w <= 12 && (double)items_per_band * ybands / slots < 8.0) ybands = 2 * ybands < max_yb ? 2 * ybands : max_yb;
-  if (const char *e = getenv("AA_FUSED_YBANDS")) {
+  if (const char *e = aa_knob("AA_FUSED_YBANDS")) {
     const int64_t v = atoll(e);
     if (v >= 1 && v <= max_yb) ybands = v;
   }
@@ -405,7 +405,7 @@ int launch_k(FusedF32Params p, const AAProblem &q) {
   // strips of a band share a workgroup unless single-strip workgroups put more waves on a CU (see aa_fused_u8_v3_impl.h)
   int spb = p.strips_per_block;
   if (spb > 1 && (resident(spb) < 0 || resident(1) > resident(spb) * spb)) spb = 1;
-  if (const char *e = getenv("AA_F32_SPB")) {  // experiment knob
+  if (const char *e = aa_knob("AA_F32_SPB")) {  // experiment knob
     const int v = atoi(e);
     if (v >= 1 && v <= 8 && resident(v) > 0) spb = v;
   }
@@ -419,7 +419,7 @@ int launch_k(FusedF32Params p, const AAProblem &q) {
   p.n_groups = planes * (int64_t)p.ybands;
   const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
-  if (getenv("AA_F32_DEBUG"))
+  if (aa_knob("AA_F32_DEBUG"))
     fprintf(stderr, "f32: NQ=%d G=%d MAXC=%d DT=%d CS=%d nstrips=%d spb=%d resident=%d ybands=%d planes=%lld grid=%lld lds=%zu\n", NQ, G, MAXC, DT, CS,
             p.nstrips, spb, resident(spb), p.ybands, (long long)planes, (long long)grid, lds_blk);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, q.in, q.out,

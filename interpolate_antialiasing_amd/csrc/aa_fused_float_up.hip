@@ -400,7 +400,7 @@ int pick_ybands_up(int64_t items_per_band, int waves_per_item, double slots, int
   // of several strips (906-wide gradients: 4 strips with the pacing barrier) measured best with the round model below.
   const double target_waves = 20.0 * aa_device_cu_count();
   const double waves_per_band = (double)items_per_band * waves_per_item;
-  if (waves_per_item == 1 && waves_per_band <= target_waves * 1.25 && !getenv("AA_FUSED_YBANDS")) {
+  if (waves_per_item == 1 && waves_per_band <= target_waves * 1.25 && !aa_knob("AA_FUSED_YBANDS")) {
     int64_t yb = (int64_t)(target_waves / (waves_per_band > 0 ? waves_per_band : 1) + 0.5);
     yb = yb < 1 ? 1 : (yb > max_yb ? max_yb : yb);
     if (yb > 64) yb = 64;
@@ -416,7 +416,7 @@ int pick_ybands_up(int64_t items_per_band, int waves_per_item, double slots, int
       ybands = yb;
     }
   }
-  if (const char *e = getenv("AA_FUSED_YBANDS")) {
+  if (const char *e = aa_knob("AA_FUSED_YBANDS")) {
     const int64_t v = atoll(e);
     if (v >= 1 && v <= max_yb) ybands = v;
   }
@@ -438,7 +438,7 @@ int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
   };
   // strips of a band share a workgroup unless single-strip workgroups put more waves on a CU (see aa_fused_u8_v3_impl.h)
   int spb = p.strips_per_block;
-  if (const char *e = getenv("AA_UP_SPB")) {  // experiment knob
+  if (const char *e = aa_knob("AA_UP_SPB")) {  // experiment knob
     const int v = atoi(e);
     if (v >= 1 && v <= 8) spb = v;
   }
@@ -452,7 +452,7 @@ int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
   p.n_groups = planes * (int64_t)p.ybands;
   const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
-  if (getenv("AA_UP_DEBUG"))
+  if (aa_knob("AA_UP_DEBUG"))
     fprintf(stderr, "up: U=%d KR=%d CPL=%d nstrips=%d spb=%d resident=%d ybands=%d groups=%lld grid=%lld lds=%zu nt=%d\n", U, KR, CPL, p.nstrips, spb,
             resident(spb), p.ybands, (long long)p.n_groups, (long long)grid, lds_blk, p.store_nt);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, (const float *)q.in, (float *)q.out,
@@ -536,20 +536,21 @@ int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   p.nseg = g.nseg;
   p.seg_bytes = p.nseg * 16;
   p.gather_off = q.ah.gather_off;
-  p.store_nt = ((p.total_out_bytes > (64ull << 20) || getenv("AA_UP_FORCE_NT")) && !getenv("AA_UP_NO_NT")) ? 1 : 0;  // (FORCE: tests of the store forms at small sizes)
+  p.store_nt = g_aa_store_form < 0 ? (p.total_out_bytes > (64ull << 20) ? 1 : 0) : (g_aa_store_form ? 1 : 0);  // (aa_set_store_form: tests of the
+                                                                                                               // streaming forms at small sizes)
   // rows or planes that are not whole 64-byte sectors: stream only the whole sectors of each piece (see the store)
-  if (p.store_nt && g.cpl == 4 && ((((uintptr_t)q.out) | (uint64_t)q.oW * 4u | p.plane_out_bytes) & 63u) != 0 && !getenv("AA_UP_NO_SPLIT"))
+  if (p.store_nt && g.cpl == 4 && ((((uintptr_t)q.out) | (uint64_t)q.oW * 4u | p.plane_out_bytes) & 63u) != 0 && !aa_knob("AA_UP_NO_SPLIT"))
     p.store_nt = 2;
   // ... and when the rows are 8-byte but not 16-byte aligned (oW = 906): strips cut at the sector boundaries of each row instead
   // (see the store).  Measured, [256,3,196,320] gradients -> 438 x W (ms, split + pacing | sector-aligned pieces): W = 898 0.347 | 0.312,
   // 906 0.321 | 0.301-0.311; rows that are 16-byte aligned are better off with the split: 900 0.257 | 0.303, 904 0.269 | 0.284
-  if (p.store_nt == 2 && q.oW % 4 == 2 && ((uintptr_t)q.out & 15) == 0 && !getenv("AA_UP_NO_ALN")) {
+  if (p.store_nt == 2 && q.oW % 4 == 2 && ((uintptr_t)q.out & 15) == 0 && !aa_knob("AA_UP_NO_ALN")) {
     p.store_nt = 3;
     p.strip_w = 240;
     p.nstrips = (int)((q.oW + 14 + 239) / 240);
     p.strips_per_block = p.nstrips <= 8 ? p.nstrips : 4;
   }
-  p.pace_all = getenv("AA_UP_PACE_ALL") ? 1 : 0;
+  p.pace_all = aa_knob("AA_UP_PACE_ALL") ? 1 : 0;
   p.ybands = 1;
   p.n_groups = 0;
   const size_t lds = (size_t)AA_UP_G * p.seg_bytes + (p.store_nt == 3 ? 1088 : 0);  // per strip: stage ring (+ the aligned-store staging area)

@@ -363,7 +363,7 @@ int aa_try_fused_u8_nhwc(const AAProblem &q, const char **variant) {
       ybands = yb;
     }
   }
-  if (const char *e = getenv("AA_FUSED_YBANDS")) {  // tuning knob for experiments; not used by tests or bench
+  if (const char *e = aa_knob("AA_FUSED_YBANDS")) {  // tuning knob for experiments; not used by tests or bench
     const int64_t v = atoll(e);
     if (v >= 1 && v <= max_yb) ybands = v;
   }

@@ -97,7 +97,7 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   // all strips of a band in one workgroup when they fit (<= 8 waves); wider images: groups of 4 strips
   p.strips_per_block = p.nstrips <= 8 ? p.nstrips : 4;
   p.spb_forced = 0;
-  if (const char *e = getenv("AA_V3_SPB")) {  // experiment knob
+  if (const char *e = aa_knob("AA_V3_SPB")) {  // experiment knob
     const int v = atoi(e);
     if (v >= 1 && v <= 8) { p.strips_per_block = v; p.spb_forced = 1; }
   }

@@ -651,7 +651,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 // staged rows per wave: 8; developer builds (-DAA_V2_TUNING) read AA_V3_G
 inline int aa_v3_group() {
 #ifdef AA_V2_TUNING
-  if (const char *e = getenv("AA_V3_G")) return atoi(e);
+  if (const char *e = aa_knob("AA_V3_G")) return atoi(e);
 #endif
   return 8;
 }
@@ -673,7 +673,7 @@ int pick_ybands(int64_t items_per_band, double slots, int taps_h, int64_t H, int
       ybands = yb;
     }
   }
-  if (const char *e = getenv("AA_FUSED_YBANDS")) {  // experiment knob
+  if (const char *e = aa_knob("AA_FUSED_YBANDS")) {  // experiment knob
     const int64_t v = atoll(e);
     if (v >= 1 && v <= max_yb) ybands = v;
   }
@@ -698,7 +698,7 @@ int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
   const size_t lds_blk = lds * spb;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   p.ybands = pick_ybands(p.n_images * sgroups, (double)aa_device_cu_count() * resident(spb), taps_h, q.H, q.oH);
-  if (getenv("AA_V3_DEBUG"))
+  if (aa_knob("AA_V3_DEBUG"))
     fprintf(stderr, "[aa v3] strips %d spb %d (resident(1) %d, resident(%d) %d) ybands %d lds/strip %zu images %lld\n", p.nstrips, spb,
             resident(1), p.nstrips <= 8 ? p.nstrips : 4, resident(p.nstrips <= 8 ? p.nstrips : 4), p.ybands, lds, (long long)p.n_images);
   const int64_t groups8 = (p.n_images * (int64_t)p.ybands + 7) / 8 * 8;  // whole rounds of the 8 XCDs (see the kernel)

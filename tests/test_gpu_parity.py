@@ -1055,13 +1055,12 @@ def test_u8_growing_heights_take_the_fused_gather_form(aa):
 def test_backward_store_forms_agree(aa):
     """The up-scaling / backward kernel stores large outputs with the streaming policy in three forms chosen from the row pitch:
     whole pieces (rows of whole 64-byte sectors), pieces cut at each row's sector boundaries through an LDS shift (even widths),
-    and split policies with a pacing barrier (odd widths).  AA_UP_FORCE_NT applies them at test sizes: each must equal the generic
+    and split policies with a pacing barrier (odd widths).  aa_set_store_form(1) applies them at test sizes: each must equal the generic
     path bit for bit, for widths that end strips in every way (exactly full, two columns over, a short last strip)."""
-    import os
     from interpolate_antialiasing_amd import _lib
 
     torch.manual_seed(9)
-    os.environ["AA_UP_FORCE_NT"] = "1"
+    assert _lib.set_store_form(1) == -1
     try:
         for (h, w), (oh, ow) in (((196, 320), (438, 906)), ((50, 100), (131, 466)), ((50, 100), (77, 468)), ((40, 200), (90, 494)),
                                  ((60, 90), (61, 258)), ((33, 300), (100, 905)), ((20, 128), (64, 512)), ((30, 400), (65, 1202))):
@@ -1085,7 +1084,7 @@ def test_backward_store_forms_agree(aa):
             assert va == "fused_f32_nchw_up" and torch.equal(a, b), (va, (h, w), (oh, ow))
     finally:
         _lib.set_fused(1)
-        del os.environ["AA_UP_FORCE_NT"]
+        assert _lib.set_store_form(-1) == 1
 
 
 @pytest.mark.gpu

@@ -2,7 +2,10 @@
 """Distil gpurun_out/pmc_<tag>/ (tools/pmc_any.sh) into a committed summary: profiles/<out>.json with the averaged counters of the
 dominant kernel, its rocprofv3 --kernel-trace --stats line, and the derived numbers DESIGN.md quotes (HBM traffic with the guide's
 gfx950 FETCH_SIZE x2 correction, ratio to the algorithmic bytes, LDS conflict share, instructions per wave).
-usage: tools/pmc_digest.py TAG KERNEL_SUBSTRING OUT_NAME ALG_BYTES [BATCH]"""
+The summary is stamped with the fingerprint of the kernel's sources (interpolate_antialiasing_amd/_lib.py KERNEL_SOURCES; bench.py
+compares it with the tree it runs from and prints "traffic_stale") and with the register / LDS figures of the profiled kernel read
+from the built code objects (csrc/*.o).
+usage: tools/pmc_digest.py TAG KERNEL_SUBSTRING OUT_NAME ALG_BYTES [BATCH] [VARIANT]"""
 import csv
 import glob
 import json
@@ -11,6 +14,7 @@ import sys
 
 tag, kern, out_name, alg = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
 batch = int(sys.argv[5]) if len(sys.argv) > 5 else None
+variant = sys.argv[6] if len(sys.argv) > 6 else None
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = os.path.join(root, "gpurun_out", f"pmc_{tag}")
 res = {}
@@ -57,7 +61,53 @@ if g("GRBM_GUI_ACTIVE") and g("SQ_ACTIVE_INST_SCA") is not None:
     derived["scalar_busy_share (SQ_ACTIVE_INST_SCA x 4 / (1024 SIMDs x cycles))"] = round(g("SQ_ACTIVE_INST_SCA") * 4.0 / (1024.0 * g("GRBM_GUI_ACTIVE") / 8.0), 4)
 if g("GRBM_GUI_ACTIVE") and g("SQ_LDS_IDX_ACTIVE") is not None:
     derived["lds_busy_share (SQ_LDS_IDX_ACTIVE / (256 CUs x cycles))"] = round(g("SQ_LDS_IDX_ACTIVE") / (256.0 * g("GRBM_GUI_ACTIVE") / 8.0), 4)
+
+
+def code_object_figures(demangled_name):
+    """{vgpr_count, sgpr_count, lds_bytes, scratch_bytes} of the kernel whose demangled name starts like `demangled_name`, from the
+    code objects embedded in csrc/*.o (None when the ROCm LLVM tools or the objects are missing)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objdump, readelf, filt = (os.path.join(llvm, t) for t in ("llvm-objdump", "llvm-readelf", "llvm-cxxfilt"))
+    if not all(os.path.exists(t) for t in (objdump, readelf, filt)):
+        return None
+    want = re.sub(r"\s+", "", demangled_name.split("(")[0].replace("void ", ""))
+    for obj in sorted(glob.glob(os.path.join(root, "interpolate_antialiasing_amd", "csrc", "*.o"))):
+        with tempfile.TemporaryDirectory() as td:
+            shutil.copy(obj, os.path.join(td, "x.o"))
+            if subprocess.run([objdump, "--offloading", "x.o"], cwd=td, capture_output=True).returncode != 0:
+                continue
+            for co in [f for f in os.listdir(td) if "gfx950" in f]:
+                notes = subprocess.run([readelf, "--notes", os.path.join(td, co)], capture_output=True, text=True).stdout
+                for blk in notes.split("- .agpr_count")[1:]:
+                    m = re.search(r"\.name:\s+(\S+)", blk)
+                    if not m:
+                        continue
+                    dem = subprocess.run([filt, m.group(1)], capture_output=True, text=True).stdout.strip()
+                    if re.sub(r"\s+", "", dem.split("(")[0].replace("void ", "")) != want:
+                        continue
+                    num = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1)) if re.search(r"\." + k + r":\s+(\d+)", blk) else None
+                    return {"object": os.path.basename(obj), "vgpr_count": num("vgpr_count"), "sgpr_count": num("sgpr_count"),
+                            "static_lds_bytes": num("group_segment_fixed_size"), "scratch_bytes": num("private_segment_fixed_size")}
+    return None
+
+
 out = {"workload_tag": tag, "kernel_substring": kern, "kernel_trace_stats": stats, "derived": derived}
+if variant:
+    sys.path.insert(0, root)
+    from interpolate_antialiasing_amd import _lib
+
+    out["variant"] = variant
+    out["source_fingerprint"] = _lib.source_fingerprint(variant)
+if stats:
+    try:
+        out["code_object"] = code_object_figures(stats["kernel"])
+    except Exception as e:  # never lose a summary over the decoration
+        out["code_object"] = {"error": str(e)[:200]}
 if batch:
     out["batch"] = batch
 out.update(res)
