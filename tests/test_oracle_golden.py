@@ -4,10 +4,14 @@ The fixtures were produced by tests/golden/make_golden.py from the reference's o
 reference's data/ PNGs, Pillow and fp64 autograd; this file re-checks the oracle against them wherever it
 runs (build container and GPU box), so the checker itself is pinned before any GPU parity test trusts it.
 """
+import os
+
 import numpy as np
 import pytest
 
 import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FILTS = ("linear", "cubic", "box")
 
@@ -136,3 +140,24 @@ def test_empty_batch_and_errors():
     assert oracle.forward("linear", x, (4, 4)).shape == (0, 3, 4, 4)
     with pytest.raises(RuntimeError):
         oracle.forward("linear", np.zeros((1, 1, 4, 4), np.float32), (0, 4))
+
+
+def test_oracle_edge_cases_under_asan():
+    """The reference found its one memory bug with AddressSanitizer (README.md:507-520: step_two_dot_one's `j < 2` unroll read a tap
+    past a one-tap window at the last row; fixed at step_two_dot_two/aa_interpolation_impl.h:45-51,75-80).  The C restatement gets the
+    same treatment: `make -C oracle asan` builds it with -fsanitize=address,undefined next to a driver (oracle/asan_edge.c) that runs
+    out = 1, in < ksize, in = out, up-scaling and one-pixel-wide shapes x 3 filters x align_corners through every entry point with
+    exact-size heap buffers; any access one element past a window aborts the run."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None and shutil.which("cc") is None:
+        pytest.skip("no C compiler")
+    odir = os.path.join(ROOT, "oracle")
+    b = subprocess.run(["make", "-C", odir, "asan"], capture_output=True, text=True, timeout=600)
+    if b.returncode != 0 and "sanitize" in (b.stderr + b.stdout) and "cannot find" in (b.stderr + b.stdout):
+        pytest.skip("this toolchain has no libasan")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([os.path.join(odir, "_asan", "asan_edge")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="2"))
+    assert r.returncode == 0 and "ASAN_EDGE_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
