@@ -89,9 +89,10 @@ typedef struct aa_table_header {
                             their full weights in w[] above) */
   int32_t reserved[1];
 } aa_table_header;
-/* Scatter section (AA_TABLE_PIL and AA_TABLE_F32 tables), used by the fused kernels whose vertical pass runs in registers:
- * one 32-byte record per INPUT index x (in_size + 1 records; the last is an all-zero sentinel a reader may prefetch):
- * { int32 first, int32 count | completes << 16, int32 w[6] }.  first = the first output whose window ends at or after
+/* Scatter section (every table kind), used by the fused kernels whose vertical pass runs in registers: one record per INPUT
+ * index x (in_size + 1 records; the last is an all-zero sentinel a reader may prefetch).  AA_TABLE_PIL / AA_TABLE_F32: 32-byte
+ * records { int32 first, int32 count | completes << 16, int32 (PIL) or float (F32) w[6] }; AA_TABLE_F64: 64-byte records
+ * { int32 first, int32 count | completes << 16, double w[6], 8 bytes of padding }.  first = the first output whose window ends at or after
  * x; first .. first+count-1 = the outputs whose window holds x, w[k] = weight[first+k][x - xmin[first+k]] (zero
  * padded); completes = how many outputs, starting at `first`, have x as the LAST index of their window (they can be
  * emitted once x has been absorbed).  Present only when count <= 6 everywhere. */

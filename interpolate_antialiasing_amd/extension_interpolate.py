@@ -272,9 +272,15 @@ def _axis_pass_2d(L, x, y, dt, kind, outer, n_in, n_out, inner, table, dev, stre
     images in which only one axis changes — [1,1,outer,n] -> [1,1,outer,n_out] when inner == 1 (the pass runs along rows),
     [outer,1,n,inner] -> [outer,1,n_out,inner] otherwise (along columns) — and the other axis gets the IDENTITY table (box filter,
     same size: one tap of weight exactly 1.0, so x * 1.0 = x bit for bit and no neighbour is ever touched).  Same bytes moved as
-    the generic single-axis kernel, but through the streaming kernels.  Returns False (caller runs the generic axis kernel) for
-    sizes the 2-D entry point cannot index."""
+    the generic single-axis kernel, but through the streaming kernels.  Returns False (caller runs the single-axis kernel
+    aa_resample_axis_fwd, one launch, no workspace) whenever that would NOT be one fused launch: sizes the 2-D entry point cannot
+    index, a problem no fused kernel takes (aa_workspace_bytes answers non-zero: the two-launch path would add an identity pass and
+    a full-size intermediate, twice the traffic of the single-axis kernel), the fused kernels switched off, and rows so short that
+    the identity table (one record per row of the stack) would outweigh them."""
+    es = x.element_size()
     if inner == 1:
+        if n_in * es < 4 * 84 or outer > (1 << 22):  # identity table: ~84 bytes per row of the stack, cached per distinct `outer`
+            return False
         n2, h2, w2, oh2, ow2 = 1, outer, n_in, outer, n_out
         th = tables.get_table(_lib.FILTER_BOX, kind, outer, outer, False, 0.0, dev)
         tw = table
@@ -285,10 +291,11 @@ def _axis_pass_2d(L, x, y, dt, kind, outer, n_in, n_out, inner, table, dev, stre
     if max(h2, w2, oh2, ow2) >= (1 << 24):
         return False
     ah, aw = th.axis(), tw.axis()
-    ws_bytes = L.aa_workspace_bytes(dt, _lib.NCHW, n2, 1, h2, w2, oh2, ow2, ctypes.byref(ah), ctypes.byref(aw))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-    rc = L.aa_resample_fwd(x.data_ptr(), y.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, dt, _lib.NCHW,
-                           n2, 1, h2, w2, ctypes.byref(ah), ctypes.byref(aw), stream)
+    if L.aa_workspace_bytes(dt, _lib.NCHW, n2, 1, h2, w2, oh2, ow2, ctypes.byref(ah), ctypes.byref(aw)) != 0:
+        return False  # no fused kernel for this pass (or they are disabled): the single-axis kernel is the cheaper form
+    rc = L.aa_resample_fwd(x.data_ptr(), y.data_ptr(), None, 0, dt, _lib.NCHW, n2, 1, h2, w2, ctypes.byref(ah), ctypes.byref(aw), stream)
+    if rc == -6:  # AA_ERR_WORKSPACE: a pointer-dependent decline (an unaligned view) after the shape said yes
+        return False
     _lib.check(rc, "aa_resample_fwd (axis pass)")
     return True
 

@@ -75,15 +75,23 @@ class WeightTable:
 
     # ---- inspection (tests) ----------------------------------------------------------------------------
     def unpack_scatter(self):
-        """-> (first int32[in], count int32[in], w int32[in, scatter_ksize], completes int32[in]) (CPU numpy)."""
+        """-> (first int32[in], count int32[in], w [in, 6], completes int32[in]) (CPU numpy).  Record layout by table kind
+        (include/aa_interp.h): PIL / F32 tables 32 bytes {int32 first, int32 count | completes << 16, int32 / float w[6]};
+        F64 tables 64 bytes {int32 first, int32 count | completes << 16, double w[6], 8 bytes padding}."""
         import numpy as np
 
         if not self.scatter_off:
             return None
         raw = self.buf.detach().cpu().numpy()
         n, off = self.in_size, self.scatter_off
+        if self.kind == _lib.TABLE_F64:
+            blk = raw[off:off + 64 * n].reshape(n, 64)
+            head = blk[:, :8].copy().view(np.int32).reshape(n, 2)
+            w = blk[:, 8:56].copy().view(np.float64).reshape(n, 6)
+            return head[:, 0], head[:, 1] & 0xFFFF, w, head[:, 1] >> 16
         rec = raw[off:off + 32 * n].view(np.int32).reshape(n, 8).copy()
-        return rec[:, 0], rec[:, 1] & 0xFFFF, rec[:, 2:], rec[:, 1] >> 16
+        w = rec[:, 2:] if self.kind == _lib.TABLE_PIL else rec[:, 2:].copy().view(np.float32)
+        return rec[:, 0], rec[:, 1] & 0xFFFF, w, rec[:, 1] >> 16
 
     def unpack(self):
         """-> (xmin int32[out], xsize int32[out], w [out,ksize]) as CPU numpy arrays."""

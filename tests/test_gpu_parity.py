@@ -56,6 +56,19 @@ def test_device_tables_bit_exact(aa, golden_tables):
         assert np.array_equal(xsize, golden_tables[key + "_xsize"]), key
         assert np.array_equal(w, golden_tables[key + "_w"]), key
         assert t.max_taps == max(1, int(xsize.max())), key
+        sc = t.unpack_scatter()  # float tables carry the adjoint-form records too: 32-byte (float) or 64-byte (double) records
+        if sc is not None and t.scatter_max <= 6:
+            first, count, sw, completes = sc
+            assert sw.dtype == (np.float32 if kind == _lib.TABLE_F32 else np.float64)
+            last = xmin + np.maximum(xsize, 1) - 1
+            dense = np.zeros((int(n_in), int(n_out)), w.dtype)
+            for o in range(int(n_out)):
+                dense[xmin[o]:xmin[o] + xsize[o], o] = w[o, :xsize[o]]
+            for x in range(int(n_in)):
+                fed = np.nonzero((xmin <= x) & (last >= x))[0]
+                assert count[x] == len(fed) and (len(fed) == 0 or first[x] == fed[0]), (key, x)
+                assert np.array_equal(sw[x, :count[x]], dense[x, first[x]:first[x] + count[x]]) and not sw[x, count[x]:].any(), (key, x)
+            assert completes.sum() == int(n_out), key
         n += 1
     assert n >= 40
 
@@ -529,6 +542,20 @@ def test_nd_passes_take_the_fused_kernels(aa):
         assert torch.equal(y1, y0), (tuple(x.shape), size)
     exp = _oracle_axis("linear", x1[:1].cpu().numpy(), 2, 1300)
     assert np.array_equal(aa.linear_forward_nd(x1[:1], [1300]).cpu().numpy(), exp)
+    # passes that would NOT be one fused launch go to the single-axis kernel (one launch, no workspace), never to the two-launch path
+    # with an identity pass: the fused kernels switched off, fp64 with growing sizes (no fused kernel), rows too short for the
+    # identity table to pay (round-2 advisor finding)
+    xd = torch.rand(2, 2, 500, device="cuda", dtype=torch.float64)
+    xs = torch.rand(4, 3, 40, device="cuda")
+    for fn, x, size, fused in ((aa.linear_forward_nd, x1, [1300], 0), (aa.linear_forward_nd, xd, [700], 1), (aa.linear_forward_nd, xs, [17], 1)):
+        try:
+            _lib.set_fused(fused)
+            y = fn(x, size)
+            v = _lib.last_variant()
+        finally:
+            _lib.set_fused(1)
+        assert v == "generic_axis", (v, tuple(x.shape), size, fused)
+        assert np.array_equal(y[:1].cpu().numpy(), _oracle_axis("linear", x[:1].cpu().numpy(), 2, size[0]))
     g = torch.randn(4, 3, 1300, device="cuda", dtype=torch.float64)
     try:
         _lib.set_fused(1)
