@@ -210,7 +210,14 @@ def secondary_configs(dev):
     x = torch.rand(64, 3, 1024, 1024, device=dev) * 255
     add("configs[2]: fp32 NCHW [64,3,1024,1024]->[224,224] bicubic", lambda: aa.cubic_forward(x, [224, 224]),
         64 * 3 * 4 * (1024 * 1024 + 224 * 224))
-    del x
+    add("configs[2] in the opt-in tolerance mode (precision='fast': FMA accumulation, <= 1e-4 relative; the line above is bit-exact)",
+        lambda: aa.cubic_forward(x, [224, 224], precision="fast"), 64 * 3 * 4 * (1024 * 1024 + 224 * 224))
+    xh = x.half()
+    add("fp16 NCHW [64,3,1024,1024]->[224,224] bilinear, bit-exact half(reference_fp32)", lambda: aa.linear_forward(xh, [224, 224]),
+        64 * 3 * 2 * (1024 * 1024 + 224 * 224))
+    add("fp16 NCHW [64,3,1024,1024]->[224,224] bilinear, tolerance mode", lambda: aa.linear_forward(xh, [224, 224], precision="fast"),
+        64 * 3 * 2 * (1024 * 1024 + 224 * 224))
+    del x, xh
     x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
     add("configs[3] per-GPU shard: uint8 channels_last [1024,3,906,438]->[320,196] bilinear", lambda: aa.linear_forward(x, [320, 196]),
         1024 * 3 * (906 * 438 + 320 * 196))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AA_INTERP_ABI_VERSION 2
+#define AA_INTERP_ABI_VERSION 3 /* 3: aa_resample_fwd_ex (flags), aa_set_store_form; every v2 entry point unchanged */
 
 typedef void *aa_stream_t; /* hipStream_t */
 
@@ -167,6 +167,17 @@ size_t aa_workspace_bytes(int dtype, int layout, int64_t N, int64_t C, int64_t H
 int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
                     int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
                     aa_stream_t stream);
+
+/* The same with flags.  AA_FLAG_FAST — the opt-in TOLERANCE mode for f32 / f16 / bf16 images: the caller accepts results within
+ * 1e-4 relative of the reference's (BASELINE.json's float bar) instead of bit-identical ones, and the fused kernels then accumulate
+ * with fused multiply-adds over zero-padded windows (no separately rounded product and sum, no per-position select).  Differences
+ * are rounding only (~1e-7 relative); a NaN / Inf input value additionally poisons every output whose 16-byte-aligned window
+ * holds it (0 * inf), not only those whose taps do.  Ignored for u8 and f64 images and wherever no tolerance kernel applies (the
+ * exact kernels run: bit-identical results are always within tolerance).  aa_workspace_bytes() answers for both. */
+#define AA_FLAG_FAST 1u
+int aa_resample_fwd_ex(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
+                       int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
+                       unsigned flags, aa_stream_t stream);
 
 /* Decode-adjacent forward: uint8 image in, float32 tensor out, ONE launch.  Replaces what the reference's harness
  * does around the op on the CPU — np.asarray(pil) -> transpose(2,0,1) -> .float() -> op (test.py:337-339,55; README.md:416

@@ -210,6 +210,13 @@ size_t aa_workspace_bytes(int dtype, int layout, int64_t N, int64_t C, int64_t H
 int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
                     int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
                     aa_stream_t stream) {
+  return aa_resample_fwd_ex(in_dev, out_dev, workspace_dev, workspace_bytes, dtype, layout, N, C, H, W, ax_h, ax_w, 0u, stream);
+}
+
+int aa_resample_fwd_ex(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
+                       int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
+                       unsigned flags, aa_stream_t stream) {
+  if (flags & ~(unsigned)AA_FLAG_FAST) return AA_ERR_BAD_SHAPE;
   if (dtype < AA_U8 || dtype > AA_BF16) return AA_ERR_BAD_DTYPE;
   if (layout != AA_NCHW && layout != AA_NHWC) return AA_ERR_BAD_LAYOUT;
   if (N < 0 || C <= 0 || H <= 0 || W <= 0) return AA_ERR_BAD_SHAPE;
@@ -231,11 +238,13 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
   p.N = N; p.C = C; p.H = H; p.W = W; p.oH = ax_h->out_size; p.oW = ax_w->out_size;
   p.ah = *ax_h; p.aw = *ax_w;
   p.stream = (hipStream_t)stream;
+  p.fast = (flags & AA_FLAG_FAST) && dtype != AA_U8 && dtype != AA_F64 ? 1 : 0;  // (integer and double arithmetic have no tolerance mode)
 
   const char *variant = "none";
   rc = 0;
   if (g_fused_enabled) {
-    if (g_fused_enabled == 1) rc = aa_try_fused_u8_nhwc_v3(p, &variant);
+    if (g_fused_enabled == 1 && p.fast) rc = aa_try_fused_float_nchw_fast(p, &variant);  // declines -> the exact kernels (always within tolerance)
+    if (rc == 0 && g_fused_enabled == 1) rc = aa_try_fused_u8_nhwc_v3(p, &variant);
     if (rc == 0) rc = aa_try_fused_u8_nhwc(p, &variant);
     if (rc == 0) rc = aa_try_fused_float_nchw(p, &variant);
     if (rc == 0) rc = aa_try_fused_float_nchw_up(p, &variant);

@@ -94,6 +94,7 @@ struct AAProblem {
   int normalize = 0;
   float mean[4] = {0.f, 0.f, 0.f, 0.f};
   float std[4] = {1.f, 1.f, 1.f, 1.f};
+  int fast = 0;  // AA_FLAG_FAST: the caller accepts results within 1e-4 relative of the reference's (FMA accumulation)
 };
 
 // generic two-launch separable path (always available); returns variant name through *variant
@@ -106,6 +107,8 @@ int aa_launch_generic_convert(const AAProblem &p, const char **variant);  // u8 
 int aa_try_fused_u8_nhwc(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw(const AAProblem &p, const char **variant);
 int aa_try_fused_float_nchw_up(const AAProblem &p, const char **variant);  // H <= oH: adjoint (gather form), up-scaling
+int aa_try_fused_float_nchw_fast(const AAProblem &p, const char **variant);  // tolerance mode (aa_fused_float.hip built with -DAA_F32_FAST_BUILD)
+bool aa_fused_float_nchw_fast_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah, const aa_axis *aw);
 int aa_try_fused_u8_nhwc_v3(const AAProblem &p, const char **variant);  // LDS-DMA staged, wave-autonomous, V pass in registers
 // The *_applicable predicates hold EVERY reason a fused path can decline that does not depend on the pointers (shape, LDS
 // size, grid size, dispatch widths): aa_workspace_bytes() answers 0 exactly when aa_resample_fwd() will not need one.

@@ -29,10 +29,27 @@
 
 #include "aa_common.h"
 
+// This file is compiled twice (Makefile): as it stands — the reference's arithmetic, bit for bit — and with -DAA_F32_FAST_BUILD into
+// aa_fused_float_fast.o: the opt-in TOLERANCE mode (AA_FLAG_FAST, `precision="fast"`): every window position is one fused
+// multiply-add with a zero weight outside the lane's own taps (no separately rounded product and sum, no v_cndmask, no lane masks)
+// and the vertical pass accumulates with FMAs too.  Results then differ from the reference's by rounding only (BASELINE.json's
+// north star allows 1e-4 relative; measured ~1e-7), and a non-finite value poisons every output whose 16-byte ALIGNED window holds it
+// (0 * inf), not only those whose taps do.  The fast build holds the plane kernels for fp32 / fp16 / bf16 only.
+#ifdef AA_F32_FAST_BUILD
+#define AA_F32_FAST 1
+#define aa_fused_float_nchw_applicable aa_fused_float_nchw_fast_applicable
+#define aa_try_fused_float_nchw aa_try_fused_float_nchw_fast
+#else
+#define AA_F32_FAST 0
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline float fma_real(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ inline double fma_real(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 struct FusedF32Params {
   int H, W, oH, oW;  // W, oW: ELEMENTS per row (pixels * channel stride for interleaved channels)
@@ -295,6 +312,10 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
       else if constexpr (DT == AA_F64) dq = __longlong_as_double(((unsigned long long)d[q >> 1][2 * (q & 1) + 1] << 32) | d[q >> 1][2 * (q & 1)]);
       else if constexpr (DT == AA_F32) dq = __uint_as_float(d[q >> 2][q & 3]);
       else dq = elem_to_f32<DT>(d[q >> 3][(q >> 1) & 3] >> (16 * (q & 1)));
+      if constexpr (AA_F32_FAST != 0) {  // tolerance mode: the weight is zero outside the lane's own taps
+        acc = fma_real(dq, wreg[q], acc);
+        continue;
+      }
       const real prod = dq * wreg[q];
       if constexpr (AA_F32_ANDMASK != 0) {
         acc = sub_masked(acc, prod, mk[q]);
@@ -310,14 +331,14 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
     if (__builtin_expect(idx0 == 0, 1)) {
 #pragma unroll
       for (int k2 = 0; k2 < MAXC; k2++)
-        if (k2 < cnt) A[k2] = A[k2] + acc * sc.w[k2];  // wave-uniform: only the outputs whose window holds this row
+        if (k2 < cnt) A[k2] = AA_F32_FAST ? fma_real(acc, sc.w[k2], A[k2]) : A[k2] + acc * sc.w[k2];  // wave-uniform: only the outputs whose window holds this row
     } else if (idx0 < 0 && idx0 > -MAXC) {
 #pragma unroll
       for (int s = 1; s < MAXC; s++) {
         if (idx0 == -s) {
 #pragma unroll
           for (int k2 = s; k2 < MAXC; k2++)
-            if (k2 < cnt) A[k2 - s] = A[k2 - s] + acc * sc.w[k2];
+            if (k2 < cnt) A[k2 - s] = AA_F32_FAST ? fma_real(acc, sc.w[k2], A[k2 - s]) : A[k2 - s] + acc * sc.w[k2];
         }
       }
     }
@@ -512,6 +533,7 @@ bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw
 bool aa_fused_float_nchw_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah,
                                     const aa_axis *aw) {
   if (dtype != AA_F32 && dtype != AA_F16 && dtype != AA_BF16 && dtype != AA_F64) return false;
+  if (AA_F32_FAST && (dtype == AA_F64 || (layout == AA_NHWC && C > 1))) return false;  // (the tolerance build: planes of fp32 / fp16 / bf16)
   if (layout != AA_NCHW && layout != AA_NHWC) return false;
   const int want_kind = dtype == AA_F64 ? AA_TABLE_F64 : AA_TABLE_F32;
   if (!ah || !aw || ah->kind != want_kind || aw->kind != want_kind) return false;
@@ -553,9 +575,12 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
 
   int rc = 0;
   const int mc = q.ah.scatter_max;
+#if !AA_F32_FAST
   if (g.cs == 3) rc = launch_interleaved<3>(g.nq, mc, p, q);
   else if (g.cs == 4) rc = launch_interleaved<4>(g.nq, mc, p, q);
-  else if (q.dtype == AA_F32) {
+  else
+#endif
+  if (q.dtype == AA_F32) {
     switch (g.nq) {
       case 2: rc = launch_q<2, AA_F32>(mc, p, q); break;
       case 3: rc = launch_q<3, AA_F32>(mc, p, q); break;
@@ -563,6 +588,7 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
       case 5: rc = launch_q<5, AA_F32>(mc, p, q); break;
       default: rc = launch_q<7, AA_F32>(mc, p, q); break;
     }
+#if !AA_F32_FAST
   } else if (q.dtype == AA_F64) {
     switch (g.nq) {
       case 2: rc = launch_q<2, AA_F64>(mc, p, q); break;
@@ -571,13 +597,18 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
       case 8: rc = launch_q<8, AA_F64>(mc, p, q); break;
       default: rc = launch_q<11, AA_F64>(mc, p, q); break;
     }
+#endif
   } else if (q.dtype == AA_F16) {
     rc = g.nq == 2 ? launch_q<2, AA_F16>(mc, p, q) : launch_q<3, AA_F16>(mc, p, q);
   } else {
     rc = g.nq == 2 ? launch_q<2, AA_BF16>(mc, p, q) : launch_q<3, AA_BF16>(mc, p, q);
   }
+#if AA_F32_FAST
+  if (rc == 1) *variant = q.dtype == AA_F32 ? "fused_f32_nchw_fast" : (q.dtype == AA_F16 ? "fused_f16_nchw_fast" : "fused_bf16_nchw_fast");
+#else
   if (rc == 1 && g.cs != 1) *variant = "fused_f32_nhwc";
   else if (rc == 1 && q.dtype == AA_F64) *variant = "fused_f64_nchw";
   else if (rc == 1) *variant = q.dtype == AA_F32 ? "fused_f32_nchw" : (q.dtype == AA_F16 ? "fused_f16_nchw" : "fused_bf16_nchw");
+#endif
   return rc;
 }

@@ -20,6 +20,9 @@ Differences, all additive:
     default ``uint8_mode="pil"`` is bit-exact with PIL.Image.resize (integer arithmetic, uint8 intermediate);
     ``uint8_mode="harness"`` reproduces test.py:52-58,72,75 (float(), fp32 op, clamp for bicubic, truncating byte());
   * the backward is the TRUE adjoint of the antialiased forward (the reference header's is the non-AA one, SURVEY §0.3);
+  * ``precision="fast"`` (f32 / f16 / bf16): the opt-in tolerance mode — FMA accumulation, results within 1e-4 relative of the
+    reference's (BASELINE.json's float bar) instead of bit-identical; the default ``"exact"`` rounds product and sum separately in
+    the reference's tap order.  In fast mode a NaN / Inf pixel also reaches outputs whose 16-byte-aligned window holds it;
   * the same callables are registered as ``torch.ops.extension_interpolate.*``.
 """
 from __future__ import annotations
@@ -116,9 +119,12 @@ def _user_scales(scale_factors, n: int):
 
 def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequence[int], align_corners: bool,
              uint8_mode: Optional[str] = None, scale_factors: Optional[Sequence[float]] = None, out_dtype=None,
-             out_format: Optional[str] = None, mean=None, std=None) -> torch.Tensor:
+             out_format: Optional[str] = None, mean=None, std=None, precision: Optional[str] = None) -> torch.Tensor:
     if not isinstance(input, torch.Tensor):
         raise TypeError(f"{name}(): argument 'input' must be Tensor")
+    if precision not in (None, "exact", "fast"):
+        raise ValueError("precision must be 'exact' (default: the reference's results bit for bit) or 'fast' (within 1e-4 relative)")
+    flags = _lib.FLAG_FAST if precision == "fast" else 0
     if out_dtype is not None or out_format is not None or mean is not None or std is not None:
         if input.dtype != torch.uint8 or out_dtype not in (None, torch.float32):
             raise NotImplementedError("out_dtype / out_format / mean / std: the fused conversion takes uint8 input and gives float32")
@@ -162,12 +168,12 @@ def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequen
     ah, aw, ws_bytes, pah, paw = plan[:5]
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
     if dev.index == cur:
-        rc = L.aa_resample_fwd(x.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, dt, layout,
-                               n, c, h, w, pah, paw, torch.cuda.current_stream(dev).cuda_stream)
+        rc = L.aa_resample_fwd_ex(x.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, dt, layout,
+                                  n, c, h, w, pah, paw, flags, torch.cuda.current_stream(dev).cuda_stream)
     else:
         with torch.cuda.device(dev):
-            rc = L.aa_resample_fwd(x.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, dt,
-                                   layout, n, c, h, w, pah, paw, torch.cuda.current_stream(dev).cuda_stream)
+            rc = L.aa_resample_fwd_ex(x.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, dt,
+                                      layout, n, c, h, w, pah, paw, flags, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, name)
     return out
 
@@ -428,26 +434,26 @@ def nearest_forward_nd(input: torch.Tensor, output_size: Sequence[int], align_co
 # ---- the reference's callables ---------------------------------------------------------------------------
 def linear_forward(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False, *,
                     uint8_mode: Optional[str] = None, scale_factors: Optional[Sequence[float]] = None, out_dtype=None,
-                    out_format: Optional[str] = None, mean=None, std=None) -> torch.Tensor:
+                    out_format: Optional[str] = None, mean=None, std=None, precision: Optional[str] = None) -> torch.Tensor:
     """Anti-Aliased Linear Interpolation forward (s2.2/extension_interpolate.cpp:7-14,47)."""
     return _forward(_lib.FILTER_LINEAR, "linear_forward", input, output_size, align_corners, uint8_mode, scale_factors, out_dtype, out_format,
-                    mean, std)
+                    mean, std, precision)
 
 
 def nearest_forward(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False, *,
                     uint8_mode: Optional[str] = None, scale_factors: Optional[Sequence[float]] = None, out_dtype=None,
-                    out_format: Optional[str] = None, mean=None, std=None) -> torch.Tensor:
+                    out_format: Optional[str] = None, mean=None, std=None, precision: Optional[str] = None) -> torch.Tensor:
     """Anti-Aliased "Nearest" (really: box filter) forward (s2.2/extension_interpolate.cpp:26-33,48)."""
     return _forward(_lib.FILTER_BOX, "nearest_forward", input, output_size, align_corners, uint8_mode, scale_factors, out_dtype, out_format,
-                    mean, std)
+                    mean, std, precision)
 
 
 def cubic_forward(input: torch.Tensor, output_size: Sequence[int], align_corners: bool = False, *,
                     uint8_mode: Optional[str] = None, scale_factors: Optional[Sequence[float]] = None, out_dtype=None,
-                    out_format: Optional[str] = None, mean=None, std=None) -> torch.Tensor:
+                    out_format: Optional[str] = None, mean=None, std=None, precision: Optional[str] = None) -> torch.Tensor:
     """Anti-Aliased Cubic Interpolation forward (s2.2/extension_interpolate.cpp:35-42,49)."""
     return _forward(_lib.FILTER_CUBIC, "cubic_forward", input, output_size, align_corners, uint8_mode, scale_factors, out_dtype, out_format,
-                    mean, std)
+                    mean, std, precision)
 
 
 def linear_backward(grad_output: torch.Tensor, output_size: Sequence[int], input_size: Sequence[int],

@@ -1114,6 +1114,117 @@ def test_backward_store_forms_agree(aa):
         assert _lib.set_store_form(-1) == 1
 
 
+def test_fast_precision_mode_is_within_tolerance(aa, golden_forward):
+    """precision="fast" (AA_FLAG_FAST): FMA accumulation over zero-padded windows.  Bar: BASELINE.json's float tolerance, 1e-4
+    relative to the reference's CPU path (here: the oracle, which the exact mode equals bit for bit) on BASELINE configs 0 and 2 and
+    the reference-derived goldens; a fast kernel must really have run for the plane layouts; the default stays bit-exact.
+    Documented non-finite behaviour: a NaN reaches every output whose window holds it (as in exact mode) and may additionally reach
+    outputs whose 16-byte-aligned read window holds it — never anything further than 3 columns beyond, never another row band."""
+    from interpolate_antialiasing_amd import _lib
+
+    rng = np.random.default_rng(77)
+    for filt, shape, size in (("linear", (2, 3, 438, 906), (196, 320)), ("cubic", (1, 3, 1024, 1024), (224, 224)),
+                              ("cubic", (2, 3, 61, 53), (17, 23)), ("linear", (2, 3, 100, 300), (37, 128))):
+        x = (rng.random(shape, dtype=np.float32) * 255).astype(np.float32)
+        exp = oracle.forward(filt, x, size, nthreads=8)
+        xt = _gpu(x)
+        y_exact = _fn(aa, filt)(xt, list(size))
+        assert np.array_equal(y_exact.cpu().numpy(), exp), (filt, shape)
+        y_fast = _fn(aa, filt)(xt, list(size), precision="fast")
+        assert _lib.last_variant() == "fused_f32_nchw_fast", (_lib.last_variant(), filt, shape)
+        np.testing.assert_allclose(y_fast.cpu().numpy(), exp, rtol=1e-4, atol=1e-4 * 255)  # tolerance of the north star, stated here
+        rel = np.abs(y_fast.cpu().numpy() - exp).max() / 255.0
+        assert rel < 1e-5, rel  # (what it actually is: rounding only)
+        # 16-bit floats: half(fast_fp32) against half(oracle): one unit in the last place at most
+        xh = xt.half()
+        yh = _fn(aa, filt)(xh, list(size), precision="fast")
+        assert _lib.last_variant() == "fused_f16_nchw_fast" or shape[-1] < 64, _lib.last_variant()
+        yh_exact = _fn(aa, filt)(xh, list(size))
+        np.testing.assert_allclose(yh.float().cpu().numpy(), yh_exact.float().cpu().numpy(), rtol=2e-3, atol=0.25)
+    # the reference-derived goldens (outputs of the reference's own build), fp32 plane layout
+    n = 0
+    for case in sorted({k.split("_")[0] for k in golden_forward.files}):
+        x = golden_forward[f"{case}_x"]
+        size = [int(v) for v in golden_forward[f"{case}_size"]]
+        ac = bool(golden_forward[f"{case}_align"])
+        for filt in FILTS:
+            exp = golden_forward[f"{case}_{filt}_f32"]
+            got = _fn(aa, filt)(_gpu(x), size, ac, precision="fast").cpu().numpy()
+            np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(exp).max())))
+            n += 1
+    assert n >= 15
+    # layouts / dtypes without a tolerance kernel run the exact ones (always within tolerance), uint8 ignores the flag
+    xcl = _gpu((rng.random((2, 3, 120, 200), dtype=np.float32) * 255).astype(np.float32), channels_last=True)
+    assert torch.equal(aa.linear_forward(xcl, [50, 80], precision="fast"), aa.linear_forward(xcl, [50, 80]))
+    xd = torch.rand(1, 2, 90, 130, device="cuda", dtype=torch.float64)
+    assert torch.equal(aa.linear_forward(xd, [40, 60], precision="fast"), aa.linear_forward(xd, [40, 60]))
+    x8 = torch.randint(0, 256, (2, 3, 120, 200), dtype=torch.uint8, device="cuda")
+    assert torch.equal(aa.linear_forward(x8, [50, 80], precision="fast"), aa.linear_forward(x8, [50, 80]))
+    with pytest.raises(ValueError):
+        aa.linear_forward(xcl, [50, 80], precision="sloppy")
+    # non-finite behaviour
+    x = (rng.random((1, 1, 120, 400), dtype=np.float32) * 255).astype(np.float32)
+    x[0, 0, 60, 200] = np.nan
+    xt = _gpu(x)
+    ne = torch.isnan(aa.linear_forward(xt, [50, 100])).cpu().numpy()[0, 0]
+    nf = torch.isnan(aa.linear_forward(xt, [50, 100], precision="fast")).cpu().numpy()[0, 0]
+    assert ne.any() and (nf | ~ne).all(), "fast mode must poison at least the outputs exact mode poisons"
+    rows_e, cols_e = np.nonzero(ne.any(1))[0], np.nonzero(ne.any(0))[0]
+    rows_f, cols_f = np.nonzero(nf.any(1))[0], np.nonzero(nf.any(0))[0]
+    assert rows_f.min() == rows_e.min() and rows_f.max() == rows_e.max()  # vertical windows are exact in both modes
+    assert cols_f.min() >= cols_e.min() - 3 and cols_f.max() <= cols_e.max() + 3, (cols_e, cols_f)
+
+
+def test_tensors_beyond_4_gib(aa):
+    """The reference indexes with int64_t throughout (s2.2/aa_interpolation_impl.h:688-699); SURVEY 8(d) config 4 in fp32 is 4.88 GB
+    per GPU.  The kernels address an image / plane with 32-bit offsets from a 64-bit base and clamp their buffer ranges: here a
+    tensor's bytes run past 4 GiB (and past 2^31 elements for uint8), for both headline layouts.  Every image: fused == generic
+    two-launch path (independent implementations); first / middle / last image and the first one beyond the 4 GiB mark: == oracle."""
+    from interpolate_antialiasing_amd import _lib
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * (1 << 30):
+        pytest.skip(f"needs ~24 GiB of free HBM, {free >> 30} GiB free")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    # fp32 NCHW [1024,3,906,438] -> [320,196] (4.88 GB in), uint8 channels_last [4096,3,438,906] -> [196,320] (4.88 GB, 4.9e9 elements)
+    for case in ("f32", "u8"):
+        if case == "f32":
+            x = torch.rand((1024, 3, 906, 438), device="cuda", generator=gen) * 255
+            size, img_bytes = [320, 196], 3 * 906 * 438 * 4
+        else:
+            x = torch.randint(0, 256, (4096, 438, 906, 3), dtype=torch.uint8, device="cuda", generator=gen).permute(0, 3, 1, 2)
+            size, img_bytes = [196, 320], 3 * 438 * 906
+        assert x.numel() * x.element_size() > (1 << 32)
+        try:
+            _lib.set_fused(1)
+            y1 = aa.linear_forward(x, size)
+            v1 = _lib.last_variant()
+            _lib.set_fused(0)
+            y0 = aa.linear_forward(x, size)
+            v0 = _lib.last_variant()
+        finally:
+            _lib.set_fused(1)
+        assert v1.startswith("fused") and v0.startswith("generic"), (v1, v0)
+        assert torch.equal(y1, y0), (case, v1, v0)
+        del y0
+        n = x.shape[0]
+        beyond = (1 << 32) // img_bytes + 1  # the first image that lies entirely past the 4 GiB mark
+        for i in sorted({0, n // 2, beyond, n - 1}):
+            xi = x[i:i + 1].cpu().numpy()
+            exp = oracle.forward("linear", xi, tuple(size), nthreads=8) if case == "f32" else oracle.pil_resize_u8("linear", xi, tuple(size), nthreads=8)
+            assert np.array_equal(y1[i:i + 1].cpu().numpy(), exp), (case, i)
+        if case == "f32":  # the true adjoint at the same size: 0.77 GB of gradients -> 4.88 GB
+            g = torch.randn((1024, 3, 320, 196), device="cuda", generator=gen)
+            gi = aa.linear_backward(g, size, [1024, 3, 906, 438])
+            for i in (0, beyond, 1023):
+                exp = oracle.backward("linear", g[i:i + 1].cpu().numpy(), (906, 438))
+                assert np.abs(gi[i:i + 1].cpu().numpy() - exp).max() < 1e-4, i
+            del g, gi
+        del x, y1
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.gpu
 def test_bench_rank_path_through_the_launcher():
     """The multi-rank code path end to end on hardware, as a fresh process: `bench.py --gpus 1 --force-launcher` makes the parent

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.aa_abi_version() == 2
+    assert L.aa_abi_version() == 3
     assert L.aa_device_count() >= 0  # 0 on the CPU-only build box, never throws
     assert _lib.strerror(-2).startswith("dtype")
 

@@ -18,6 +18,12 @@ if name == "headline":
 elif name == "c2":
     x = torch.rand(64, 3, 1024, 1024, device=dev) * 255
     fn = lambda: aa.cubic_forward(x, [224, 224])
+elif name == "c2fast":
+    x = torch.rand(64, 3, 1024, 1024, device=dev) * 255
+    fn = lambda: aa.cubic_forward(x, [224, 224], precision="fast")
+elif name == "c2f16fast":
+    x = (torch.rand(64, 3, 1024, 1024, device=dev) * 255).half()
+    fn = lambda: aa.linear_forward(x, [224, 224], precision="fast")
 elif name == "c0f32":
     x = torch.rand(256, 3, 438, 906, device=dev) * 255
     fn = lambda: aa.linear_forward(x, [196, 320])
