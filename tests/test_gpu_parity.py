@@ -545,9 +545,8 @@ def test_nd_passes_take_the_fused_kernels(aa):
     # passes that would NOT be one fused launch go to the single-axis kernel (one launch, no workspace), never to the two-launch path
     # with an identity pass: the fused kernels switched off, fp64 with growing sizes (no fused kernel), rows too short for the
     # identity table to pay (round-2 advisor finding)
-    xd = torch.rand(2, 2, 500, device="cuda", dtype=torch.float64)
     xs = torch.rand(4, 3, 40, device="cuda")
-    for fn, x, size, fused in ((aa.linear_forward_nd, x1, [1300], 0), (aa.linear_forward_nd, xd, [700], 1), (aa.linear_forward_nd, xs, [17], 1)):
+    for fn, x, size, fused in ((aa.linear_forward_nd, x1, [1300], 0), (aa.linear_forward_nd, xs, [17], 1)):
         try:
             _lib.set_fused(fused)
             y = fn(x, size)
@@ -556,6 +555,11 @@ def test_nd_passes_take_the_fused_kernels(aa):
             _lib.set_fused(1)
         assert v == "generic_axis", (v, tuple(x.shape), size, fused)
         assert np.array_equal(y[:1].cpu().numpy(), _oracle_axis("linear", x[:1].cpu().numpy(), 2, size[0]))
+    xd = torch.rand(1, 2, 40, 60, 70, device="cuda", dtype=torch.float64)  # the depth axis GROWS: fp64 has no fused kernel for growing heights
+    yd = aa.linear_forward_nd(xd, [50, 60, 70])
+    # (passes run last axis first: W and H keep their size = identity passes through the fused kernel, then the depth pass declines)
+    assert _lib.last_variant() == "generic_axis", _lib.last_variant()
+    assert np.array_equal(yd.cpu().numpy(), _oracle_axis("linear", xd.cpu().numpy(), 2, 50))
     g = torch.randn(4, 3, 1300, device="cuda", dtype=torch.float64)
     try:
         _lib.set_fused(1)
@@ -1138,7 +1142,8 @@ def test_fast_precision_mode_is_within_tolerance(aa, golden_forward):
         # 16-bit floats: half(fast_fp32) against half(oracle): one unit in the last place at most
         xh = xt.half()
         yh = _fn(aa, filt)(xh, list(size), precision="fast")
-        assert _lib.last_variant() == "fused_f16_nchw_fast" or shape[-1] < 64, _lib.last_variant()
+        if filt == "linear":  # (21-tap bicubic windows are beyond the 16-bit kernels' 17 taps: generic path, exact arithmetic)
+            assert _lib.last_variant() == "fused_f16_nchw_fast", _lib.last_variant()
         yh_exact = _fn(aa, filt)(xh, list(size))
         np.testing.assert_allclose(yh.float().cpu().numpy(), yh_exact.float().cpu().numpy(), rtol=2e-3, atol=0.25)
     # the reference-derived goldens (outputs of the reference's own build), fp32 plane layout

@@ -57,6 +57,10 @@ elif name == "bwd_f64":
 elif name == "up":
     x = torch.rand(64, 3, 438, 906, device=dev) * 255
     fn = lambda: aa.linear_forward(x, [1200, 1200])
+elif name.startswith("bwdw:"):  # bwdw:<W> : the backward of config A with W input columns (the 906-column residue study)
+    wcols = int(name.split(":")[1])
+    x = torch.randn(256, 3, 196, 320, device=dev)
+    fn = lambda: aa.linear_backward(x, [196, 320], [256, 3, 438, wcols])
 elif name.startswith("custom:"):  # custom:<u8|u8h|f32|f16>:<nchw|nhwc>:<linear|cubic>:<oW>:<oH>:<B>   (input 438x906x3)
     _, dt, lay, filt, ow, oh, b = name.split(":")
     x = torch.randint(0, 256, (int(b), 438, 906, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
