@@ -168,7 +168,7 @@ def cpu_baseline(seconds: float = 12.0):
     }
 
 
-def secondary_configs(dev):
+def secondary_configs(dev, with_atomics=False):
     """Short timings (rank 0, N=1, after the headline's timed region) of the other BASELINE.json configs, so that every
     round's BENCH json carries them: algorithmic GB/s = (input + output bytes) / event time.  Not the headline metric."""
     from interpolate_antialiasing_amd import _lib, extension_interpolate as aa
@@ -233,8 +233,10 @@ def secondary_configs(dev):
     g = torch.randn(256, 3, 196, 320, device=dev)
     add("configs[4] batched: backward fp32 grad [256,3,196,320]->[256,3,438,906], gather form (true adjoint)",
         lambda: aa.linear_backward(g, [196, 320], [256, 3, 438, 906]), 256 * 3 * 4 * (438 * 906 + 196 * 320))
-    add("configs[4] batched, scatter-add ATOMICS form (API parity; the gather form above is the product path)",
-        lambda: aa.linear_backward(g, [196, 320], [256, 3, 438, 906], atomic=True), 256 * 3 * 4 * (438 * 906 + 196 * 320))
+    if with_atomics:  # the scatter-add form is kept for API parity with BASELINE configs[4]'s wording only (two memsets, an HBM intermediate,
+        # one atomic per tap: 7 ms, 40x the gather form above); it is not a product path, so the default line does not carry it
+        add("configs[4] batched, scatter-add ATOMICS form (API parity only; --with-atomics)",
+            lambda: aa.linear_backward(g, [196, 320], [256, 3, 438, 906], atomic=True), 256 * 3 * 4 * (438 * 906 + 196 * 320))
     g1 = torch.randn(1, 3, 196, 320, device=dev)
     add("configs[4] as written: backward fp32 grad [1,3,196,320]->[1,3,438,906], gather form (latency)",
         lambda: aa.linear_backward(g1, [196, 320], [1, 3, 438, 906]), 3 * 4 * (438 * 906 + 196 * 320))
@@ -286,6 +288,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short timings of the other BASELINE configs")
+    ap.add_argument("--with-atomics", action="store_true", help="secondary: also time the scatter-add atomics form of the backward (API parity path)")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="exercise the rank launcher only: every rank prints its rendezvous environment and exits before any "
                          "GPU call; rank 0 also prints the bench line's skeleton (n_gpus, global_batch).  Runs without a GPU.")
@@ -500,7 +503,7 @@ def main(argv=None):
             out["secondary"], out["cpu_baseline"] = None, None
             out["n1_only"] = "secondary, cpu_baseline and the copy ceiling are measured at --gpus 1 only"
         else:
-            out["secondary"] = None if args.no_secondary else secondary_configs(dev)
+            out["secondary"] = None if args.no_secondary else secondary_configs(dev, args.with_atomics)
             out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if use_dist:
