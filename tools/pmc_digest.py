@@ -72,10 +72,15 @@ def code_object_figures(demangled_name):
     import tempfile
 
     llvm = "/opt/rocm/lib/llvm/bin"
-    objdump, readelf, filt = (os.path.join(llvm, t) for t in ("llvm-objdump", "llvm-readelf", "llvm-cxxfilt"))
-    if not all(os.path.exists(t) for t in (objdump, readelf, filt)):
+    objdump, readelf = (os.path.join(llvm, t) for t in ("llvm-objdump", "llvm-readelf"))
+    filt = os.path.join(llvm, "llvm-cxxfilt") if os.path.exists(os.path.join(llvm, "llvm-cxxfilt")) else shutil.which("c++filt")
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and filt):
         return None
-    want = re.sub(r"\s+", "", demangled_name.split("(")[0].replace("void ", ""))
+    def norm(n):  # name with its template arguments, without return type, parameter list and white space
+        n = n.replace("(anonymous namespace)", "@anon@").replace("void ", "")
+        return re.sub(r"\s+", "", n.split("(")[0]).rstrip(">")
+
+    want = norm(demangled_name)
     for obj in sorted(glob.glob(os.path.join(root, "interpolate_antialiasing_amd", "csrc", "*.o"))):
         with tempfile.TemporaryDirectory() as td:
             shutil.copy(obj, os.path.join(td, "x.o"))
@@ -88,7 +93,8 @@ def code_object_figures(demangled_name):
                     if not m:
                         continue
                     dem = subprocess.run([filt, m.group(1)], capture_output=True, text=True).stdout.strip()
-                    if re.sub(r"\s+", "", dem.split("(")[0].replace("void ", "")) != want:
+                    have = norm(dem)
+                    if not (have.startswith(want) or want.startswith(have)):  # (one side may print trailing default arguments)
                         continue
                     num = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1)) if re.search(r"\." + k + r":\s+(\d+)", blk) else None
                     return {"object": os.path.basename(obj), "vgpr_count": num("vgpr_count"), "sgpr_count": num("sgpr_count"),
