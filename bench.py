@@ -226,6 +226,9 @@ def secondary_configs(dev, with_atomics=False):
     add("decode-adjacent: uint8 HWC [1024,906,438,3] -> float32 NCHW [1024,3,320,196] in one launch (+ mean/std)",
         lambda: aa.linear_forward(x, [320, 196], out_dtype=torch.float32, out_format="nchw", mean=[123.675, 116.28, 103.53],
                                   std=[58.395, 57.12, 57.375]), 1024 * 3 * (906 * 438 + 4 * 320 * 196))
+    add("decode-adjacent in the opt-in tolerance mode (precision='fast': FMAs in both passes, float32 output within 1e-4 relative)",
+        lambda: aa.linear_forward(x, [320, 196], out_dtype=torch.float32, out_format="nchw", mean=[123.675, 116.28, 103.53],
+                                  std=[58.395, 57.12, 57.375], precision="fast"), 1024 * 3 * (906 * 438 + 4 * 320 * 196))
     x = x.contiguous()
     add("uint8 NCHW (planar) [1024,3,906,438]->[320,196] bilinear", lambda: aa.linear_forward(x, [320, 196]),
         1024 * 3 * (906 * 438 + 320 * 196))

@@ -172,8 +172,10 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
  * 1e-4 relative of the reference's (BASELINE.json's float bar) instead of bit-identical ones, and the fused kernels then accumulate
  * with fused multiply-adds over zero-padded windows (no separately rounded product and sum, no per-position select).  Differences
  * are rounding only (~1e-7 relative); a NaN / Inf input value additionally poisons every output whose 16-byte-aligned window
- * holds it (0 * inf), not only those whose taps do.  Ignored for u8 and f64 images and wherever no tolerance kernel applies (the
- * exact kernels run: bit-identical results are always within tolerance).  aa_workspace_bytes() answers for both. */
+ * holds it (0 * inf), not only those whose taps do.  u8 images with AA_TABLE_F32 tables (the harness's float arithmetic) have the
+ * mode too: FMAs in both passes, so the truncated byte may differ from the exact mode's by one count.  Ignored for Pillow's integer
+ * arithmetic, for f64 images and wherever no tolerance kernel applies (the exact kernels run: bit-identical results are always
+ * within tolerance).  aa_workspace_bytes() answers for both. */
 #define AA_FLAG_FAST 1u
 int aa_resample_fwd_ex(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
                        int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
@@ -190,6 +192,7 @@ typedef struct aa_convert {
   int32_t normalize;  /* 0: raw op result */
   float mean[4];
   float std[4];
+  uint32_t flags;     /* 0, or AA_FLAG_FAST: the tolerance mode (fused multiply-adds; results within 1e-4 relative of the exact mode's) */
 } aa_convert;
 size_t aa_workspace_bytes_u8_to_f32(int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
                                     const aa_convert *cv);

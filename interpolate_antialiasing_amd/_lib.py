@@ -52,7 +52,7 @@ class Axis(ctypes.Structure):
 
 class Convert(ctypes.Structure):
     _fields_ = [("out_layout", ctypes.c_int32), ("normalize", ctypes.c_int32), ("mean", ctypes.c_float * 4),
-                ("std", ctypes.c_float * 4)]
+                ("std", ctypes.c_float * 4), ("flags", ctypes.c_uint32)]
 
 
 class AAInterpError(RuntimeError):

@@ -238,12 +238,13 @@ int aa_resample_fwd_ex(const void *in_dev, void *out_dev, void *workspace_dev, s
   p.N = N; p.C = C; p.H = H; p.W = W; p.oH = ax_h->out_size; p.oW = ax_w->out_size;
   p.ah = *ax_h; p.aw = *ax_w;
   p.stream = (hipStream_t)stream;
-  p.fast = (flags & AA_FLAG_FAST) && dtype != AA_U8 && dtype != AA_F64 ? 1 : 0;  // (integer and double arithmetic have no tolerance mode)
+  // (Pillow's integer arithmetic and double arithmetic have no tolerance mode; uint8 images with AA_TABLE_F32 tables = the harness's float arithmetic do)
+  p.fast = (flags & AA_FLAG_FAST) && dtype != AA_F64 && ax_w->kind == AA_TABLE_F32 ? 1 : 0;
 
   const char *variant = "none";
   rc = 0;
   if (g_fused_enabled) {
-    if (g_fused_enabled == 1 && p.fast) rc = aa_try_fused_float_nchw_fast(p, &variant);  // declines -> the exact kernels (always within tolerance)
+    if (g_fused_enabled == 1 && p.fast && dtype != AA_U8) rc = aa_try_fused_float_nchw_fast(p, &variant);  // declines -> the exact kernels (always within tolerance)
     if (rc == 0 && g_fused_enabled == 1) rc = aa_try_fused_u8_nhwc_v3(p, &variant);
     if (rc == 0) rc = aa_try_fused_u8_nhwc(p, &variant);
     if (rc == 0) rc = aa_try_fused_float_nchw(p, &variant);
@@ -269,6 +270,8 @@ static int fill_convert(AAProblem &p, const aa_convert *cv, int64_t C) {
   p.out_layout = cv->out_layout;
   p.normalize = cv->normalize ? 1 : 0;
   for (int i = 0; i < 4; i++) { p.mean[i] = cv->mean[i]; p.std[i] = cv->std[i]; }
+  if (cv->flags & ~(uint32_t)AA_FLAG_FAST) return AA_ERR_BAD_SHAPE;
+  p.fast = (cv->flags & AA_FLAG_FAST) ? 1 : 0;
   return AA_OK;
 }
 

@@ -82,6 +82,7 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   p.outm = q.out_f32 ? (planar || q.out_layout == AA_NCHW ? 1 : 2) : 0;
   p.normalize = q.out_f32 ? q.normalize : 0;
   p.cin = (int)q.C;
+  p.fast = 0;
   p.byte_store = (!q.out_f32 && ((q.oW * C) % 4 != 0 || (C == 3 && q.oW % 4 != 0) || ((uintptr_t)q.out & 3) != 0)) ? 1 : 0;
   if (q.out_f32 && ((uintptr_t)q.out & 3) != 0) return AA_ERR_BAD_SHAPE;  // a float tensor that is not float aligned
   for (int c = 0; c < 4; c++) { p.mean[c] = q.mean[c]; p.std[c] = q.std[c]; }
@@ -120,12 +121,21 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
          : C == 4 ? aa_v3_launch_up_c4(tw, taps_h, nonneg, flt, p, q, lds)
                   : aa_v3_launch_up_c1(tw, taps_h, nonneg, flt, p, q, lds);
   } else {
+    if (flt && q.fast) {  // the tolerance mode of the float-arithmetic kernels (down-scaling heights only; growing heights run exact)
+      p.fast = 1;
+      rc = C == 3 ? aa_v3_launch_c3ff(tw, q.ah.scatter_max, p, q, lds) : C == 4 ? aa_v3_launch_c4ff(tw, q.ah.scatter_max, p, q, lds)
+                                                                                 : aa_v3_launch_c1ff(tw, q.ah.scatter_max, p, q, lds);
+    } else
     rc = C == 3   ? aa_v3_launch_c3(tw, q.ah.scatter_max, flt, p, q, lds)
          : C == 4 ? aa_v3_launch_c4(tw, q.ah.scatter_max, flt, p, q, lds)
                   : aa_v3_launch_c1(tw, q.ah.scatter_max, flt, p, q, lds);
   }
-  if (rc == 1 && q.out_f32) *variant = planar ? "fused_u8_planar_to_f32_v3" : (p.outm == 1 ? "fused_u8_nhwc_to_f32_nchw_v3" : "fused_u8_nhwc_to_f32_nhwc_v3");
-  else if (rc == 1) *variant = flt ? (planar ? "fused_u8_planar_harness_v3" : "fused_u8_nhwc_harness_v3")
+  const bool fastv = flt && q.fast && !up;
+  if (rc == 1 && q.out_f32) *variant = planar ? (fastv ? "fused_u8_planar_to_f32_v3_fast" : "fused_u8_planar_to_f32_v3")
+                                              : (p.outm == 1 ? (fastv ? "fused_u8_nhwc_to_f32_nchw_v3_fast" : "fused_u8_nhwc_to_f32_nchw_v3")
+                                                             : (fastv ? "fused_u8_nhwc_to_f32_nhwc_v3_fast" : "fused_u8_nhwc_to_f32_nhwc_v3"));
+  else if (rc == 1) *variant = flt ? (planar ? (fastv ? "fused_u8_planar_harness_v3_fast" : "fused_u8_planar_harness_v3")
+                                             : (fastv ? "fused_u8_nhwc_harness_v3_fast" : "fused_u8_nhwc_harness_v3"))
                         : (planar ? "fused_u8_planar_pil_v3" : "fused_u8_nhwc_pil_v3");
   return rc;
 }

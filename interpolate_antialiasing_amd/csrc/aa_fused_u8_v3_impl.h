@@ -58,6 +58,12 @@
 #define AA_V3_F32OUT_AUX 0  // cache policy of the float32-output stores (decode-adjacent conversion).  nt measured: NCHW output 0.478 -> 0.505 ms, NHWC unchanged: default kept
 #endif
 
+#ifndef AA_V3_FLT_FAST
+#define AA_V3_FLT_FAST 0  // 1 (aa_fused_u8_v3_c{1,3,4}ff.hip): the float-arithmetic kernels in the opt-in TOLERANCE mode (AA_FLAG_FAST): every tap of
+                          // both passes is one fused multiply-add instead of a separately rounded product and sum.  Results differ from the
+                          // reference harness's by rounding only (<= 1e-4 relative; after the truncating byte() at most one count)
+#endif
+
 #ifndef AA_V3_UNALIGNED
 #define AA_V3_UNALIGNED 0  // 1: window reads straight from the window's BYTE address (gfx950's LDS does serve unaligned
                            // ds_read_b32/b64, and hipcc emits them for align-1 pointers), saving the 5 v_alignbyte per row.
@@ -85,6 +91,7 @@ struct FusedU8V3Params {
   // byte(): what np.asarray(pil) -> transpose -> .float() -> op gives (test.py:337-339,55), optionally (v - mean) / std
   int outm, normalize, cin;
   float mean[4], std[4];
+  int fast;        // AA_FLAG_FAST on a float-arithmetic problem: the FMA instantiations (aa_fused_u8_v3_c{1,3,4}ff.hip)
   int byte_store;  // output rows that are not whole dwords (oW*C % 4 != 0, or C == 3 with oW % 4 != 0) or an output pointer that
                    // is not dword aligned: every lane stores its own bytes instead of the quad-merged dword stores
 };
@@ -467,6 +474,10 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
         for (int c = 0; c < C; c++) {
           const int bi = j * C + c;
           const float px = (float)((v[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
+          if constexpr (AA_V3_FLT_FAST != 0) {
+            accf[c] = j == 0 ? px * __int_as_float(wreg[j]) : __builtin_fmaf(px, __int_as_float(wreg[j]), accf[c]);
+            continue;
+          }
           const float prod = px * __int_as_float(wreg[j]);  // taps outside the window have weight +0.0: adding their
           accf[c] = j == 0 ? prod : accf[c] + prod;          // products never changes a value (bytes are finite)
         }
@@ -529,7 +540,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       return;
     }
     auto vmac = [&](int a, int hv, int w) -> int {  // one vertical tap
-      if constexpr (FLT) return __float_as_int(__int_as_float(a) + __int_as_float(hv) * __int_as_float(w));
+      if constexpr (FLT && AA_V3_FLT_FAST != 0) return __float_as_int(__builtin_fmaf(__int_as_float(hv), __int_as_float(w), __int_as_float(a)));
+      else if constexpr (FLT) return __float_as_int(__int_as_float(a) + __int_as_float(hv) * __int_as_float(w));
       else return a + __mul24(hv, w);
     };
     // accumulator set k is output o_base+k; this row feeds outputs sc.first .. sc.first+MAXC-1 (zero weights beyond)
@@ -818,6 +830,10 @@ int round_tw(int taps) {
 int aa_v3_launch_c1(int tw, int maxc, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c3(int tw, int maxc, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c4(int tw, int maxc, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+// float arithmetic in the tolerance mode (aa_fused_u8_v3_c{1,3,4}ff.hip)
+int aa_v3_launch_c1ff(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c3ff(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c4ff(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 // growing heights (aa_fused_u8_v3_c{1,3,4}u.hip)
 int aa_v3_launch_up_c1(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_up_c3(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);

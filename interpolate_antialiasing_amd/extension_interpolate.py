@@ -130,7 +130,7 @@ def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequen
             raise NotImplementedError("out_dtype / out_format / mean / std: the fused conversion takes uint8 input and gives float32")
         if uint8_mode == "pil":
             raise NotImplementedError("float32 output is the reference's fp32 arithmetic (uint8_mode='harness'), not Pillow's integers")
-        return _forward_to_float(filter_id, name, input, output_size, align_corners, scale_factors, out_format, mean, std)
+        return _forward_to_float(filter_id, name, input, output_size, align_corners, scale_factors, out_format, mean, std, flags)
     n, c, h, w, oh, ow = _check_sizes(input.shape, output_size)
     if input.numel() == 0 and (c == 0):  # empty batch allowed, nothing else (s2.2:747-750)
         raise RuntimeError(f"Non-empty 4D data tensor expected but got a tensor with sizes {list(input.shape)}")
@@ -179,7 +179,7 @@ def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequen
 
 
 def _forward_to_float(filter_id: int, name: str, input: torch.Tensor, output_size: Sequence[int], align_corners: bool,
-                      scale_factors, out_format: Optional[str], mean, std) -> torch.Tensor:
+                      scale_factors, out_format: Optional[str], mean, std, flags: int = 0) -> torch.Tensor:
     """Decode-adjacent forward: uint8 in, float32 out, one launch.  The reference's harness spends 0.33 of its
     2.27 ms per image on np.asarray(pil) -> transpose -> .float() before the op (test.py:337-339,55; README.md:416); here the
     uint8 bytes (HWC = channels_last, or CHW) are read directly, the op runs in the reference's fp32 arithmetic and the
@@ -197,6 +197,7 @@ def _forward_to_float(filter_id: int, name: str, input: torch.Tensor, output_siz
     cv = _lib.Convert()
     cv.out_layout = out_layout
     cv.normalize = 0
+    cv.flags = flags
     if (mean is None) != (std is None):
         raise ValueError("mean and std must be given together")
     if mean is not None:

@@ -1167,6 +1167,20 @@ def test_fast_precision_mode_is_within_tolerance(aa, golden_forward):
     assert torch.equal(aa.linear_forward(x8, [50, 80], precision="fast"), aa.linear_forward(x8, [50, 80]))
     with pytest.raises(ValueError):
         aa.linear_forward(xcl, [50, 80], precision="sloppy")
+    # uint8 in float arithmetic (the harness's semantics, the decode-adjacent conversion): the tolerance kernels really run; the float32
+    # output is within 1e-4 relative of the exact one, the truncated byte() within one count (and mostly identical)
+    x8 = torch.randint(0, 256, (3, 438, 906, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
+    for layout in ("nhwc", "nchw"):
+        xin = x8 if layout == "nhwc" else x8.contiguous()
+        f_exact = aa.linear_forward(xin, [196, 320], out_dtype=torch.float32, out_format="nchw")
+        f_fast = aa.linear_forward(xin, [196, 320], out_dtype=torch.float32, out_format="nchw", precision="fast")
+        assert _lib.last_variant().endswith("_v3_fast"), _lib.last_variant()
+        np.testing.assert_allclose(f_fast.cpu().numpy(), f_exact.cpu().numpy(), rtol=1e-4, atol=1e-4 * 255)
+        b_exact = aa.linear_forward(xin, [196, 320], uint8_mode="harness")
+        b_fast = aa.linear_forward(xin, [196, 320], uint8_mode="harness", precision="fast")
+        assert _lib.last_variant().endswith("harness_v3_fast"), _lib.last_variant()
+        diff = (b_fast.int() - b_exact.int()).abs()
+        assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 1e-3
     # non-finite behaviour
     x = (rng.random((1, 1, 120, 400), dtype=np.float32) * 255).astype(np.float32)
     x[0, 0, 60, 200] = np.nan

@@ -42,6 +42,12 @@ elif name == "harness":
 elif name == "convert":
     x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
     fn = lambda: aa.linear_forward(x, [320, 196], out_dtype=torch.float32, out_format="nchw")
+elif name == "convertfast":
+    x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+    fn = lambda: aa.linear_forward(x, [320, 196], out_dtype=torch.float32, out_format="nchw", precision="fast")
+elif name == "harnessfast":
+    x = torch.randint(0, 256, (1024, 906, 438, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+    fn = lambda: aa.linear_forward(x, [320, 196], uint8_mode="harness", precision="fast")
 elif name == "planar":
     x = torch.randint(0, 256, (1024, 3, 906, 438), dtype=torch.uint8, device=dev)
     fn = lambda: aa.linear_forward(x, [320, 196])
