@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define AA_INTERP_ABI_VERSION 3 /* 3: aa_resample_fwd_ex (flags), aa_set_store_form; every v2 entry point unchanged */
+#define AA_INTERP_ABI_VERSION 3 /* 3: aa_resample_fwd_ex (flags), aa_resample_fwd_strided, aa_set_store_form, aa_convert.flags; every other
+                                   v2 entry point unchanged */
 
 typedef void *aa_stream_t; /* hipStream_t */
 
@@ -40,7 +41,8 @@ enum aa_status {
   AA_ERR_WORKSPACE = -6,     /* workspace smaller than aa_workspace_bytes() */
   AA_ERR_KSIZE = -7,         /* ksize beyond what the kernels support */
   AA_ERR_HIP = -8,           /* a HIP runtime call failed (launch error) */
-  AA_ERR_NO_DEVICE = -9
+  AA_ERR_NO_DEVICE = -9,
+  AA_ERR_STRIDES = -10       /* aa_resample_fwd_strided: this view needs a dense copy (make one and call aa_resample_fwd) */
 };
 
 /* Filters: s2.2/aa_interpolation_impl.h:292-300 (triangle), :410-424 (Keys cubic a=-0.5), :367-372 (box;
@@ -180,6 +182,15 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
 int aa_resample_fwd_ex(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
                        int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
                        unsigned flags, aa_stream_t stream);
+
+/* Forward over a STRIDED VIEW of a larger tensor, without a copy: the reference walks arbitrary strides through TensorIterator
+ * (s2.2/aa_interpolation_impl.h:555-559), and the views a data pipeline produces — a crop x[:, :, y0:y1, x0:x1] (RandomResizedCrop),
+ * a batch slice — are read here where they lie.  in_strides = the view's strides in ELEMENTS for (N, C, H, W).  Served: rows of
+ * consecutive elements (AA_NCHW: stride_W = 1; AA_NHWC: stride_C = 1, stride_W = C), any row pitch, planes n * C + c uniformly spaced
+ * (AA_NCHW: stride_N = C * stride_C; AA_NHWC: any stride_N), and a shape one of the fused single-launch kernels takes (no workspace).
+ * Anything else returns AA_ERR_STRIDES: make a dense copy and call aa_resample_fwd.  The output is dense, in `layout`. */
+int aa_resample_fwd_strided(const void *in_dev, void *out_dev, int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W,
+                            const int64_t *in_strides, const aa_axis *ax_h, const aa_axis *ax_w, unsigned flags, aa_stream_t stream);
 
 /* Decode-adjacent forward: uint8 image in, float32 tensor out, ONE launch.  Replaces what the reference's harness
  * does around the op on the CPU — np.asarray(pil) -> transpose(2,0,1) -> .float() -> op (test.py:337-339,55; README.md:416

@@ -21,6 +21,7 @@ U8, F32, F64, F16, BF16 = 0, 1, 2, 3, 4
 NCHW, NHWC = 0, 1
 TABLE_PIL, TABLE_F32, TABLE_F64 = 0, 1, 2
 ERR_BAD_DTYPE = -2
+ERR_STRIDES = -10
 FLAG_FAST = 1
 
 # every symbol include/aa_interp.h declares (tests check the .so exports exactly these)
@@ -28,7 +29,7 @@ EXPORTS = (
     "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build_bytes", "aa_table_build",
     "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_workspace_bytes", "aa_resample_fwd",
     "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_resample_axis_fwd", "aa_set_fused",
-    "aa_last_variant", "aa_probe_copy", "aa_workspace_bytes_u8_to_f32", "aa_resample_fwd_u8_to_f32", "aa_set_store_form", "aa_resample_fwd_ex",
+    "aa_last_variant", "aa_probe_copy", "aa_workspace_bytes_u8_to_f32", "aa_resample_fwd_u8_to_f32", "aa_set_store_form", "aa_resample_fwd_ex", "aa_resample_fwd_strided",
 )
 
 
@@ -100,6 +101,8 @@ def load() -> ctypes.CDLL:
     L.aa_resample_fwd.restype = i32
     L.aa_resample_fwd_ex.argtypes = [vp, vp, vp, sz, i32, i32, i64, i64, i64, i64, ax, ax, ctypes.c_uint, vp]
     L.aa_resample_fwd_ex.restype = i32
+    L.aa_resample_fwd_strided.argtypes = [vp, vp, i32, i32, i64, i64, i64, i64, ctypes.POINTER(ctypes.c_int64), ax, ax, ctypes.c_uint, vp]
+    L.aa_resample_fwd_strided.restype = i32
     L.aa_resample_bwd.argtypes = [vp, vp, vp, sz, i32, i32, i64, i64, i64, i64, ax, ax, vp]
     L.aa_resample_bwd.restype = i32
     L.aa_resample_bwd_atomic.argtypes = [vp, vp, vp, sz, i32, i32, i64, i64, i64, i64, ax, ax, vp]

@@ -101,6 +101,7 @@ const char *aa_strerror(int status) {
     case AA_ERR_WORKSPACE: return "workspace smaller than aa_workspace_bytes()";
     case AA_ERR_KSIZE: return "filter support (ksize) beyond the supported maximum";
     case AA_ERR_HIP: return "HIP kernel launch failed";
+    case AA_ERR_STRIDES: return "input view not supported without a copy (rows must be dense, planes uniformly spaced, and a fused kernel must apply)";
     case AA_ERR_NO_DEVICE: return "no HIP device";
     default: return "unknown aa_status";
   }
@@ -213,9 +214,44 @@ int aa_resample_fwd(const void *in_dev, void *out_dev, void *workspace_dev, size
   return aa_resample_fwd_ex(in_dev, out_dev, workspace_dev, workspace_bytes, dtype, layout, N, C, H, W, ax_h, ax_w, 0u, stream);
 }
 
+static int resample_fwd_impl(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
+                             int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
+                             unsigned flags, int64_t row_pitch, int64_t img_pitch, aa_stream_t stream);
+
 int aa_resample_fwd_ex(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
                        int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
                        unsigned flags, aa_stream_t stream) {
+  return resample_fwd_impl(in_dev, out_dev, workspace_dev, workspace_bytes, dtype, layout, N, C, H, W, ax_h, ax_w, flags, 0, 0, stream);
+}
+
+int aa_resample_fwd_strided(const void *in_dev, void *out_dev, int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W,
+                            const int64_t *in_strides, const aa_axis *ax_h, const aa_axis *ax_w, unsigned flags, aa_stream_t stream) {
+  if (!in_strides) return AA_ERR_NULL;
+  if (dtype < AA_U8 || dtype > AA_BF16) return AA_ERR_BAD_DTYPE;
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0) return AA_ERR_BAD_SHAPE;
+  const int64_t es = dtype == AA_U8 ? 1 : (dtype == AA_F64 ? 8 : (dtype == AA_F32 ? 4 : 2));
+  const int64_t sN = in_strides[0], sC = in_strides[1], sH = in_strides[2], sW = in_strides[3];
+  int64_t row_pitch, img_pitch;
+  if (layout == AA_NCHW) {  // rows of W consecutive elements; planes n * C + c uniformly spaced
+    if (sW != 1 || sH < W || sC < 0 || sN < 0 || (C > 1 && N > 1 && sN != C * sC)) return AA_ERR_STRIDES;
+    row_pitch = sH * es;
+    img_pitch = (C > 1 ? sC : sN) * es;
+  } else if (layout == AA_NHWC) {  // rows of W pixels of C consecutive channels; images anywhere
+    if (sC != 1 || sW != C || sH < W * C || sN < 0) return AA_ERR_STRIDES;
+    row_pitch = sH * es;
+    img_pitch = sN * es;
+  } else {
+    return AA_ERR_BAD_LAYOUT;
+  }
+  const bool dense = row_pitch == W * (layout == AA_NHWC ? C : 1) * es && (N * (layout == AA_NCHW ? C : 1) <= 1 || img_pitch == H * row_pitch);
+  if (dense) return resample_fwd_impl(in_dev, out_dev, nullptr, 0, dtype, layout, N, C, H, W, ax_h, ax_w, flags, 0, 0, stream);
+  if (img_pitch == 0 && N * (layout == AA_NCHW ? C : 1) > 1) return AA_ERR_STRIDES;  // (a broadcast batch: make it dense)
+  return resample_fwd_impl(in_dev, out_dev, nullptr, 0, dtype, layout, N, C, H, W, ax_h, ax_w, flags, row_pitch, img_pitch ? img_pitch : H * row_pitch, stream);
+}
+
+static int resample_fwd_impl(const void *in_dev, void *out_dev, void *workspace_dev, size_t workspace_bytes, int dtype,
+                             int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ax_h, const aa_axis *ax_w,
+                             unsigned flags, int64_t row_pitch, int64_t img_pitch, aa_stream_t stream) {
   if (flags & ~(unsigned)AA_FLAG_FAST) return AA_ERR_BAD_SHAPE;
   if (dtype < AA_U8 || dtype > AA_BF16) return AA_ERR_BAD_DTYPE;
   if (layout != AA_NCHW && layout != AA_NHWC) return AA_ERR_BAD_LAYOUT;
@@ -238,6 +274,7 @@ int aa_resample_fwd_ex(const void *in_dev, void *out_dev, void *workspace_dev, s
   p.N = N; p.C = C; p.H = H; p.W = W; p.oH = ax_h->out_size; p.oW = ax_w->out_size;
   p.ah = *ax_h; p.aw = *ax_w;
   p.stream = (hipStream_t)stream;
+  p.in_row_pitch = row_pitch; p.in_img_pitch = img_pitch;
   // (Pillow's integer arithmetic and double arithmetic have no tolerance mode; uint8 images with AA_TABLE_F32 tables = the harness's float arithmetic do)
   p.fast = (flags & AA_FLAG_FAST) && dtype != AA_F64 && ax_w->kind == AA_TABLE_F32 ? 1 : 0;
 
@@ -246,15 +283,16 @@ int aa_resample_fwd_ex(const void *in_dev, void *out_dev, void *workspace_dev, s
   if (g_fused_enabled) {
     if (g_fused_enabled == 1 && p.fast && dtype != AA_U8) rc = aa_try_fused_float_nchw_fast(p, &variant);  // declines -> the exact kernels (always within tolerance)
     if (rc == 0 && g_fused_enabled == 1) rc = aa_try_fused_u8_nhwc_v3(p, &variant);
-    if (rc == 0) rc = aa_try_fused_u8_nhwc(p, &variant);
+    if (rc == 0 && !row_pitch) rc = aa_try_fused_u8_nhwc(p, &variant);  // (only the two main kernels take pitched views)
     if (rc == 0) rc = aa_try_fused_float_nchw(p, &variant);
-    if (rc == 0) rc = aa_try_fused_float_nchw_up(p, &variant);
+    if (rc == 0 && !row_pitch) rc = aa_try_fused_float_nchw_up(p, &variant);
   }
   if (rc < 0) return rc;
   if (rc == 1) {
     g_last_variant = variant;
     return AA_OK;
   }
+  if (row_pitch) return AA_ERR_STRIDES;  // no kernel for this view: the caller makes a dense copy (what the two-launch path needs anyway)
   const size_t need = aa_generic_workspace_bytes(dtype, ax_w->kind, N, C, H, p.oW);
   if (!workspace_dev || workspace_bytes < need) return AA_ERR_WORKSPACE;
   rc = aa_launch_generic_fwd(p, &variant);

@@ -94,6 +94,9 @@ struct AAProblem {
   int normalize = 0;
   float mean[4] = {0.f, 0.f, 0.f, 0.f};
   float std[4] = {1.f, 1.f, 1.f, 1.f};
+  // strided input view (aa_resample_fwd_strided): rows are dense, but consecutive rows / images (channels_last) or planes (NCHW; n * C + c,
+  // uniformly spaced) lie these many BYTES apart.  0 = the dense tensor.  Only the kernels that say so take pitched problems.
+  int64_t in_row_pitch = 0, in_img_pitch = 0;
   int fast = 0;  // AA_FLAG_FAST: the caller accepts results within 1e-4 relative of the reference's (FMA accumulation)
 };
 

@@ -58,6 +58,7 @@ struct FusedF32Params {
   int ybands, nstrips, strips_per_block, strip_w;
   int nseg, seg_bytes;
   int sc_off;
+  unsigned row_pitch;  // bytes between consecutive input rows (= W * element size for a dense tensor; larger for a cropped view)
   int store_nt;  // outputs far larger than the caches are stored with the streaming (nt) policy: -3 .. -8 % (they are written once and
                  // never read here; with the default policy they displace input rows that neighbouring strips and bands re-read)
   unsigned long long plane_in_bytes, plane_out_bytes, total_in_bytes, total_out_bytes;
@@ -223,7 +224,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   if (remaining > 0xFFFFFFFCull) remaining = 0xFFFFFFFCull;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)in + plane_off), 0, (unsigned)remaining, 0x00020000);
-  const unsigned row_bytes = (unsigned)p.W * (unsigned)ES;
+  const unsigned row_bytes = p.row_pitch;
   const int lds_base = wv * G * p.seg_bytes;
   const unsigned voff = (unsigned)lane * 16u;
 
@@ -559,9 +560,16 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
   p.Wp = (int)q.W; p.oWp = (int)q.oW;
   p.ksize_w = q.aw.ksize; p.ksize_h = q.ah.ksize;
   p.plane_in_bytes = (unsigned long long)q.H * q.W * es * (g.cs == 1 ? 1 : q.C);
+  p.row_pitch = (unsigned)(q.W * es * (g.cs == 1 ? 1 : q.C));
+  if (q.in_row_pitch) {  // a pitched view: rows / planes (images) these many bytes apart
+    if ((uint64_t)q.H * (uint64_t)q.in_row_pitch > 0x7FFFFFF0ull || (q.in_row_pitch & (es - 1)) || (q.in_img_pitch & (es - 1))) return 0;
+    p.row_pitch = (unsigned)q.in_row_pitch;
+    p.plane_in_bytes = (unsigned long long)q.in_img_pitch;
+  }
   p.plane_out_bytes = (unsigned long long)q.oH * q.oW * es * (g.cs == 1 ? 1 : q.C);
   const unsigned long long planes = (unsigned long long)(g.cs == 1 ? q.N * q.C : q.N);
-  p.total_in_bytes = p.plane_in_bytes * planes;
+  p.total_in_bytes = q.in_row_pitch ? p.plane_in_bytes * (planes - 1) + (unsigned long long)(q.H - 1) * p.row_pitch + (unsigned long long)q.W * es * (g.cs == 1 ? 1 : q.C)
+                                    : p.plane_in_bytes * planes;
   p.total_out_bytes = p.plane_out_bytes * planes;
   p.sc_off = q.ah.scatter_off;
   p.store_nt = p.total_out_bytes > (64ull << 20) ? 1 : 0;

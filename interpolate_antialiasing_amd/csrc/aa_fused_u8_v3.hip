@@ -33,7 +33,7 @@ static bool v3_shape_ok(int dtype, int layout, int64_t N, int64_t Cin, int64_t H
   int tw = round_tw(taps_w);
   if (flt && tw != 0 && tw < 6) tw = 6;  // the float variant is instantiated for windows of 6, 8, 12 and 16 taps
   if (tw == 0 || W < tw) return false;
-  if ((uint64_t)H * W * C > 0xFFFFFFF0ull || (uint64_t)oH * oW * C > 0xFFFFFFF0ull) return false;
+  if ((uint64_t)H * W * C > 0x7FFFFFF0ull || (uint64_t)oH * oW * C > 0xFFFFFFF0ull) return false;
   int span_px = aa_strip_span_px(aw, tw);
   if (span_px < 0) return false;
   int nseg = (span_px * C + 3 + 15 + 15) / 16;
@@ -77,7 +77,10 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   FusedU8V3Params p;
   p.H = (int)q.H; p.W = (int)q.W; p.oH = (int)q.oH; p.oW = (int)q.oW;
   p.ksize_w = q.aw.ksize; p.ksize_h = q.ah.ksize;
-  p.img_in_bytes = (unsigned long long)q.H * q.W * C;
+  // a pitched view (cropped / batch-sliced tensor): rows q.in_row_pitch bytes apart, images (planes) q.in_img_pitch bytes apart
+  p.row_pitch = q.in_row_pitch ? (unsigned)q.in_row_pitch : (unsigned)(q.W * C);
+  p.img_in_bytes = q.in_img_pitch ? (unsigned long long)q.in_img_pitch : (unsigned long long)q.H * q.W * C;
+  if (q.in_row_pitch && ((uint64_t)q.H * (uint64_t)q.in_row_pitch > 0x7FFFFFF0ull || up)) return 0;  // (32-bit offsets inside an image; growing heights: dense only)
   p.img_out_bytes = (unsigned long long)q.oH * q.oW * C * (q.out_f32 ? 4 : 1);
   p.outm = q.out_f32 ? (planar || q.out_layout == AA_NCHW ? 1 : 2) : 0;
   p.normalize = q.out_f32 ? q.normalize : 0;
@@ -87,7 +90,8 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   if (q.out_f32 && ((uintptr_t)q.out & 3) != 0) return AA_ERR_BAD_SHAPE;  // a float tensor that is not float aligned
   for (int c = 0; c < 4; c++) { p.mean[c] = q.mean[c]; p.std[c] = q.std[c]; }
   p.in_mis = (int)((uintptr_t)q.in & 15);
-  p.total_in_bytes = p.img_in_bytes * (unsigned long long)NI + (unsigned long long)p.in_mis;
+  p.total_in_bytes = q.in_row_pitch ? p.img_in_bytes * (unsigned long long)(NI - 1) + (unsigned long long)(q.H - 1) * p.row_pitch + (unsigned long long)q.W * C + p.in_mis
+                                    : p.img_in_bytes * (unsigned long long)NI + (unsigned long long)p.in_mis;
   p.total_out_bytes = p.img_out_bytes * (unsigned long long)NI;
   p.n_images = NI;
   p.sc_off = q.ah.scatter_off;

@@ -91,6 +91,7 @@ struct FusedU8V3Params {
   // byte(): what np.asarray(pil) -> transpose -> .float() -> op gives (test.py:337-339,55), optionally (v - mean) / std
   int outm, normalize, cin;
   float mean[4], std[4];
+  unsigned row_pitch;  // bytes between consecutive input rows (= W * C for a dense tensor; larger for a cropped view)
   int fast;        // AA_FLAG_FAST on a float-arithmetic problem: the FMA instantiations (aa_fused_u8_v3_c{1,3,4}ff.hip)
   int byte_store;  // output rows that are not whole dwords (oW*C % 4 != 0, or C == 3 with oW % 4 != 0) or an output pointer that
                    // is not dword aligned: every lane stores its own bytes instead of the quad-merged dword stores
@@ -228,7 +229,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   if (remaining > 0xFFFFFFFCull) remaining = 0xFFFFFFFCull;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)(in + base_off), 0, (unsigned)remaining, 0x00020000);
-  const unsigned row_bytes = (unsigned)p.W * C;
+  const unsigned row_bytes = p.row_pitch;
   const int lds_base = wv * G * p.seg_bytes;  // this wave's private stage ring
   const unsigned lane_lds = (unsigned)(lds_base + c_l);
   const bool dma_lane0 = lane < p.nseg;
@@ -726,7 +727,7 @@ int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
 template <int C, int TW, int G, int MAXC>
 int launch_gm(const FusedU8V3Params &p, const AAProblem &q, size_t lds, int64_t grid) {
   const bool nonneg = q.aw.filter != AA_FILTER_CUBIC && q.ah.filter != AA_FILTER_CUBIC;
-  const bool periodic = ((unsigned long long)G * (unsigned long long)p.W * C) % 16 == 0;
+  const bool periodic = ((unsigned long long)G * (unsigned long long)p.row_pitch) % 16 == 0;
   if (p.nseg > 64) {  // wide segments (large down-scales): the generic-address variant only
     return nonneg ? launch_k<C, TW, G, MAXC, true, true, false>(p, q, lds, grid)
                   : launch_k<C, TW, G, MAXC, true, false, false>(p, q, lds, grid);

@@ -88,6 +88,21 @@ def _memory_format(x: torch.Tensor):
     return x.contiguous(), _lib.NCHW
 
 
+def _pitched_view(x: torch.Tensor):
+    """A non-dense 4-D view the kernels can read where it lies (aa_resample_fwd_strided): rows of consecutive elements, any row pitch,
+    planes uniformly spaced — what a crop x[:, :, y0:y1, x0:x1] or (channels_last) a batch slice of a dense tensor is.
+    -> (layout, strides) or None."""
+    n, c, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    if min(sn, sc, sh, sw) < 0 or x.numel() == 0:
+        return None
+    if sw == 1 and sh >= w and (c == 1 or n == 1 or sn == c * sc) and (c == 1 or sc >= 1):
+        return _lib.NCHW, (sn, sc, sh, sw)
+    if sc == 1 and sw == c and sh >= w * c and c > 1:
+        return _lib.NHWC, (sn, sc, sh, sw)
+    return None
+
+
 def _table_kind(dtype: torch.dtype, uint8_mode: Optional[str]) -> int:
     if dtype in (torch.float32, torch.float16, torch.bfloat16):  # 16-bit floats compute in fp32 (SURVEY §8f-4)
         return _lib.TABLE_F32
@@ -138,7 +153,13 @@ def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequen
         raise NotImplementedError(f'"upsample_generic_Nd" not implemented for \'{_DTYPE_NAMES.get(input.dtype, str(input.dtype))}\'')
     _require_gpu(input, name)
     L = _lib.load()
-    x, layout = _memory_format(input)
+    pitched = None
+    if not (input.is_contiguous() or input.is_contiguous(memory_format=torch.channels_last)):
+        pitched = _pitched_view(input)  # a crop / batch slice: read in place when a fused kernel takes it (no .contiguous() round trip)
+    if pitched is not None:
+        x, layout = input, pitched[0]
+    else:
+        x, layout = _memory_format(input)
     kind = _table_kind(x.dtype, uint8_mode)
     if kind == _lib.TABLE_PIL and align_corners:
         raise NotImplementedError("uint8_mode='pil' has no align_corners (Pillow has none); use uint8_mode='harness'")
@@ -166,6 +187,17 @@ def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequen
             _plans.clear()
         _plans[key] = plan
     ah, aw, ws_bytes, pah, paw = plan[:5]
+    if pitched is not None:
+        strides = (ctypes.c_int64 * 4)(*pitched[1])
+        with torch.cuda.device(dev):
+            rc = L.aa_resample_fwd_strided(x.data_ptr(), out.data_ptr(), dt, layout, n, c, h, w, strides, pah, paw, flags,
+                                           torch.cuda.current_stream(dev).cuda_stream)
+        if rc != _lib.ERR_STRIDES:
+            _lib.check(rc, name)
+            return out
+        x, layout2 = _memory_format(input)  # no kernel for this view: the dense copy after all (the plan was made for this layout)
+        if layout2 != layout:
+            return _forward(filter_id, name, x, output_size, align_corners, uint8_mode, scale_factors, None, None, None, None, precision)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
     if dev.index == cur:
         rc = L.aa_resample_fwd_ex(x.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None, ws_bytes, dt, layout,

@@ -1194,6 +1194,52 @@ def test_fast_precision_mode_is_within_tolerance(aa, golden_forward):
     assert cols_f.min() >= cols_e.min() - 3 and cols_f.max() <= cols_e.max() + 3, (cols_e, cols_f)
 
 
+def test_strided_views_are_read_in_place(aa, monkeypatch):
+    """The reference walks arbitrary strides through TensorIterator (s2.2/aa_interpolation_impl.h:555-559).  The views a data pipeline
+    produces — a crop of a larger tensor (RandomResizedCrop), a batch slice — go through aa_resample_fwd_strided: the fused kernels read
+    them where they lie (rows dense, any row / image pitch), with no .contiguous() round trip; results equal those of the dense copy
+    bit for bit.  Views no kernel takes (planes not uniformly spaced, no fused kernel for the shape) still work, through the copy."""
+    from interpolate_antialiasing_amd import _lib
+
+    copies = []
+    real = aa._memory_format
+    monkeypatch.setattr(aa, "_memory_format", lambda t: (copies.append(tuple(t.shape)), real(t))[1])
+    torch.manual_seed(13)
+    big8 = torch.randint(0, 256, (5, 500, 1000, 3), dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)  # channels_last storage
+    bigf = torch.rand(3, 2, 500, 1000, device="cuda") * 255
+    cases = [
+        (big8[:, :, 31:469, 47:953], [196, 320], {}, "fused_u8_nhwc_pil_v3"),                       # crop, odd byte offsets
+        (big8[1::2, :, 31:469, 47:953], [196, 320], {}, "fused_u8_nhwc_pil_v3"),                    # crop of a batch slice
+        (big8[:, :, 2:440, 1:907], [196, 320], {"uint8_mode": "harness"}, "fused_u8_nhwc_harness_v3"),
+        (big8[:, :, 0:438, 0:906], [196, 320], {"out_dtype": None}, "fused_u8_nhwc_pil_v3"),        # crop at the origin: only the pitch differs
+        (bigf[:, :, 10:448, 20:926], [196, 320], {}, "fused_f32_nchw"),                             # fp32 planes
+        (bigf[:, :, 10:448, 21:927], [196, 320], {"precision": "fast"}, "fused_f32_nchw_fast"),
+        (bigf.half()[:, :, 5:443, 3:909], [196, 320], {}, "fused_f16_nchw"),                        # rows starting on odd halves
+        (bigf[1:2, :, 10:448, 20:926], [120, 200], {}, "fused_f32_nchw"),
+    ]
+    for view, size, kw, want in cases:
+        kw = {k: v for k, v in kw.items() if v is not None}
+        assert not view.is_contiguous() and not view.is_contiguous(memory_format=torch.channels_last)
+        copies.clear()
+        y = aa.linear_forward(view, size, **kw)
+        assert _lib.last_variant() == want, (_lib.last_variant(), want, tuple(view.shape), view.stride())
+        assert copies == [], "the view was copied"
+        dense = view.contiguous(memory_format=torch.channels_last) if view.stride(1) == 1 else view.contiguous()
+        ref = aa.linear_forward(dense, size, **kw)
+        assert torch.equal(y, ref), (want, tuple(view.shape))
+        assert y.is_contiguous(memory_format=torch.channels_last) == ref.is_contiguous(memory_format=torch.channels_last)
+    x = big8[:, :, 31:469, 47:953]
+    exp = oracle.pil_resize_u8("linear", x[:1].cpu().numpy(), (196, 320))
+    assert np.array_equal(aa.linear_forward(x, [196, 320])[:1].cpu().numpy(), exp)
+    # views that are copied: a batch slice of planes (not uniformly spaced), a transposed view, fp64 growing heights (no fused kernel)
+    for view, size in ((bigf[::2, :, 10:448, 20:926], [196, 320]), (bigf.transpose(2, 3)[:, :, 20:926, 10:448], [320, 196]),
+                       (bigf.double()[:, :, 10:100, 20:200], [200, 100])):
+        copies.clear()
+        y = aa.linear_forward(view, size)
+        assert len(copies) == 1
+        assert torch.equal(y, aa.linear_forward(view.contiguous(), size))
+
+
 def test_tensors_beyond_4_gib(aa):
     """The reference indexes with int64_t throughout (s2.2/aa_interpolation_impl.h:688-699); SURVEY 8(d) config 4 in fp32 is 4.88 GB
     per GPU.  The kernels address an image / plane with 32-bit offsets from a 64-bit base and clamp their buffer ranges: here a
