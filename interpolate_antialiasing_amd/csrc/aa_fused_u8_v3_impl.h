@@ -30,6 +30,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "aa_common.h"
 
 #ifndef AA_V3_ABL
@@ -464,7 +466,14 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
     for (int k = 0; k < NV; k++) v[k] = AA_V3_UNALIGNED ? d[k] : __builtin_amdgcn_alignbyte(d[k + 1], d[k], sa);
   };
-  auto row_step = [&](const unsigned (&v)[NV], const Scatter &sc) {
+  // `steady`: every band starts with a few rows that still feed outputs of the previous band (sc.first < o_base: their weights shift by
+  // o_base - sc.first sets); once a row has sc.first == o_base that stays so to the band's end (window ends are non-decreasing).  The
+  // unrolled row loop has two forms: the general one, and — taken once `steady` is set — one whose vertical pass has no branch on that
+  // shift.  With the branch the compiler copies the untouched accumulator set where its two sides meet: three v_mov per input row
+  // (4 % of the kernel's vector instructions) that the steady form does not have.
+  bool steady = false;
+  auto row_step = [&](const unsigned (&v)[NV], const Scatter &sc, auto steady_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
     if (AA_V3_ABL == 6) return;
     int h[C];  // the horizontal-pass result of this row: Pillow's uint8 intermediate, or (FLT) the float's bits
     if constexpr (FLT) {
@@ -548,7 +557,15 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     // accumulator set k is output o_base+k; this row feeds outputs sc.first .. sc.first+MAXC-1 (zero weights beyond)
     const int idx0 = sc.first - o_base;  // 0 in steady state; negative while the band's first rows still feed
                                          // outputs that belong to the previous band
-    if (__builtin_expect(idx0 == 0, 1)) {
+    if constexpr (STEADY) {
+#pragma unroll
+      for (int k = 0; k < MAXC; k++) {
+        if (k >= 2 && k >= (sc.cc & 0xFFFF)) break;
+#pragma unroll
+        for (int c = 0; c < C; c++) A[k][c] = vmac(A[k][c], h[c], sc.w[k]);
+      }
+    } else if (__builtin_expect(idx0 == 0, 1)) {
+      steady = true;
 #pragma unroll
       for (int k = 0; k < MAXC; k++) {
         if (k >= 2 && k >= (sc.cc & 0xFFFF)) break;  // wave-uniform: most rows feed two outputs only (a zero weight in
@@ -592,7 +609,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   // (it only waits for a few more rows than strictly necessary).
   for (int g = 0; g < n_groups; g++) {
     const int x0 = g * G;
-    if (UPK == 0 && x0 + 2 * G <= n_rows) {  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
+    // the unrolled group of G rows, in its general and its steady form (see `steady` above)
+    auto unrolled_group = [&](auto steady_tag) {
       // Not a data dependence: once per G rows the strips of a band line up, so that the 192-byte pieces they store into
       // the same output rows reach L2 within a few microseconds of each other and leave it as whole lines (measured
       // -2 %; every strip of the workgroup runs the same number of groups).
@@ -612,7 +630,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           sa1 = fetch(a + row_bytes, (i + 1) % G, d1);
           __builtin_amdgcn_sched_barrier(0);
           if (AA_V3_DMA_EARLY) { dma(a + (unsigned)G * row_bytes, i); __builtin_amdgcn_sched_barrier(0); }
-          row_step(v, sc0);
+          row_step(v, sc0, steady_tag);
         } else {
           realign(d1, sa1, v);
           __builtin_amdgcn_sched_barrier(0);
@@ -620,7 +638,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           sa0 = fetch(a + row_bytes, (i + 1) % G, d0);
           __builtin_amdgcn_sched_barrier(0);
           if (AA_V3_DMA_EARLY) { dma(a + (unsigned)G * row_bytes, i); __builtin_amdgcn_sched_barrier(0); }
-          row_step(v, sc1);
+          row_step(v, sc1, steady_tag);
         }
         if (!AA_V3_DMA_EARLY) {
           if constexpr (AA_V3_BURST == 1) {
@@ -634,6 +652,10 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
         r++;
         __builtin_amdgcn_sched_barrier(0);  // keep the unrolled rows from interleaving: it only costs registers
       }
+    };
+    if (UPK == 0 && x0 + 2 * G <= n_rows) {  // (lanes beyond the strip compute a duplicate of lane 0 and never store)
+      if (steady) unrolled_group(std::true_type{});
+      else unrolled_group(std::false_type{});
     } else {
       for (int i = 0; i < G; i++) {
         const int x = x0 + i;
@@ -651,8 +673,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           else { sc0 = load_scatter(r + 1); sa0 = fetch(a + row_bytes, (i + 1) % G, d0, false); }
         }
         unsigned v[NV];
-        if ((i & 1) == 0) { realign(d0, sa0, v); row_step(v, sc0); }
-        else { realign(d1, sa1, v); row_step(v, sc1); }
+        if ((i & 1) == 0) { realign(d0, sa0, v); row_step(v, sc0, std::false_type{}); }
+        else { realign(d1, sa1, v); row_step(v, sc1, std::false_type{}); }
         if (x + G < n_rows) dma(a + (unsigned)G * row_bytes, i);
         a += row_bytes;
         r++;
