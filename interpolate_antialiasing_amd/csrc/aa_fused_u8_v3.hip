@@ -27,11 +27,13 @@ static bool v3_shape_ok(int dtype, int layout, int64_t N, int64_t Cin, int64_t H
     // (measured, [128,3,438,906] -> 1200x1200: fused 1.14 ms, generic 0.64 ms; -> 120 columns: fused 0.123, generic 0.148)
     if (planar && oW > 256) return false;
   } else {  // the in-register scatter pass needs the H table's scatter section and at most 4 open output rows
-    if (ah.scatter_off <= 0 || ah.scatter_max <= 0 || ah.scatter_max > 4) return false;
+    if (ah.scatter_off <= 0 || ah.scatter_max <= 0 || ah.scatter_max > 6) return false;
+    if (ah.scatter_max > 4 && (flt || (aw.max_taps > 0 ? aw.max_taps : aw.ksize) <= 16)) return false;  // (6 open rows: the wide-window instantiations only)
   }
   const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
   int tw = round_tw(taps_w);
   if (flt && tw != 0 && tw < 6) tw = 6;  // the float variant is instantiated for windows of 6, 8, 12 and 16 taps
+  if (tw > 16 && (flt || up)) return false;  // windows of 17 .. 34 taps: Pillow arithmetic, shrinking heights
   if (tw == 0 || W < tw) return false;
   if ((uint64_t)H * W * C > 0x7FFFFFF0ull || (uint64_t)oH * oW * C > 0xFFFFFFF0ull) return false;
   int span_px = aa_strip_span_px(aw, tw);
@@ -129,6 +131,9 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
       p.fast = 1;
       rc = C == 3 ? aa_v3_launch_c3ff(tw, q.ah.scatter_max, p, q, lds) : C == 4 ? aa_v3_launch_c4ff(tw, q.ah.scatter_max, p, q, lds)
                                                                                  : aa_v3_launch_c1ff(tw, q.ah.scatter_max, p, q, lds);
+    } else if (tw > 16) {
+      rc = C == 3 ? aa_v3_launch_c3w(tw, q.ah.scatter_max, p, q, lds) : C == 4 ? aa_v3_launch_c4w(tw, q.ah.scatter_max, p, q, lds)
+                                                                               : aa_v3_launch_c1w(tw, q.ah.scatter_max, p, q, lds);
     } else
     rc = C == 3   ? aa_v3_launch_c3(tw, q.ah.scatter_max, flt, p, q, lds)
          : C == 4 ? aa_v3_launch_c4(tw, q.ah.scatter_max, flt, p, q, lds)

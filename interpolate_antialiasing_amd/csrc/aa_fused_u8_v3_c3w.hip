@@ -1,0 +1,7 @@
+// aa_fused_u8_v3_c3w.hip — wide-window instantiations (17 .. 34 taps) of the fused uint8 kernel (aa_fused_u8_v3_impl.h) for 3 channels per
+// pixel, Pillow arithmetic: strong down-scaling such as test.py's 906 -> 120 thumbnails (17 bilinear / 33 bicubic taps).
+#include "aa_fused_u8_v3_impl.h"
+
+int aa_v3_launch_c3w(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  return dispatch_tw_wide<3>(tw, maxc, p, q, lds);
+}

@@ -814,6 +814,29 @@ int dispatch_tw(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, 
   return 0;
 }
 
+// Wide windows (17 .. 34 taps: test.py's 906 -> 120 thumbnails have 17 bilinear / 33 bicubic taps; the reference's loop takes any
+// ids_size, s2.2:52-56,81-85): the same kernel with a longer window in registers — Pillow arithmetic, shrinking heights, generic
+// window addressing, up to 6 open output rows (what a scatter record holds).  Instantiated in aa_fused_u8_v3_c{1,3,4}w.hip.
+template <int C, int TW, int MAXC>
+int launch_wide_m(const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  const bool nonneg = q.aw.filter != AA_FILTER_CUBIC && q.ah.filter != AA_FILTER_CUBIC;
+  if (p.nseg > 64) return nonneg ? launch_k<C, TW, 8, MAXC, true, true, false>(p, q, lds, 0) : launch_k<C, TW, 8, MAXC, true, false, false>(p, q, lds, 0);
+  return nonneg ? launch_k<C, TW, 8, MAXC, false, true, false>(p, q, lds, 0) : launch_k<C, TW, 8, MAXC, false, false, false>(p, q, lds, 0);
+}
+template <int C, int TW>
+int launch_wide(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  if (maxc <= 2) return launch_wide_m<C, TW, 2>(p, q, lds);
+  if (maxc <= 3) return launch_wide_m<C, TW, 3>(p, q, lds);
+  if (maxc <= 4) return launch_wide_m<C, TW, 4>(p, q, lds);
+  return launch_wide_m<C, TW, 6>(p, q, lds);
+}
+template <int C>
+int dispatch_tw_wide(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  if (tw <= 24) return launch_wide<C, 24>(maxc, p, q, lds);
+  if (tw <= 34) return launch_wide<C, 34>(maxc, p, q, lds);
+  return 0;
+}
+
 // growing heights (gather-form vertical pass): generic window addressing, one DMA per row, no scatter accumulators.  Ring of 2
 // rows for the triangle / box filters (never negative: the intermediate needs no clamp), of 6 for everything else.
 template <int C, int TW>
@@ -841,7 +864,7 @@ int dispatch_up(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p
 }
 
 int round_tw(int taps) {
-  const int opts[] = {2, 4, 6, 8, 12, 16};
+  const int opts[] = {2, 4, 6, 8, 12, 16, 24, 34};
   for (int o : opts)
     if (taps <= o) return o;
   return 0;
@@ -857,6 +880,10 @@ int aa_v3_launch_c4(int tw, int maxc, bool flt, const FusedU8V3Params &p, const 
 int aa_v3_launch_c1ff(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c3ff(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c4ff(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+// wide windows, 17 .. 34 taps (aa_fused_u8_v3_c{1,3,4}w.hip)
+int aa_v3_launch_c1w(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c3w(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c4w(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 // growing heights (aa_fused_u8_v3_c{1,3,4}u.hip)
 int aa_v3_launch_up_c1(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_up_c3(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);

@@ -786,7 +786,8 @@ def test_workspace_answer_matches_dispatch(aa):
     for fn, shape, size, want in ((aa.cubic_forward, (2, 1750, 1750, 3), [500, 500], "fused_u8_nhwc_pil_v3"),     # 15 taps
                                   (aa.linear_forward, (1, 300, 2400, 3), [50, 400], "fused_u8_nhwc_pil_v3"),      # 13 taps
                                   (aa.linear_forward, (1, 2400, 2400, 3), [400, 400], "fused_u8_nhwc_pil_v3"),
-                                  (aa.cubic_forward, (1, 700, 1400, 4), [100, 200], "generic_2pass_u8_pil")):      # 29 taps: no fused kernel
+                                  (aa.cubic_forward, (1, 700, 1400, 4), [100, 200], "fused_u8_nhwc_pil_v3"),     # 29 taps: the 34-tap window (round 3)
+                                  (aa.cubic_forward, (1, 700, 1400, 4), [100, 100], "generic_2pass_u8_pil")):      # 57 taps: no fused kernel
         x = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
         y = fn(x, size)
         v = _lib.last_variant()
@@ -1192,6 +1193,39 @@ def test_fast_precision_mode_is_within_tolerance(aa, golden_forward):
     rows_f, cols_f = np.nonzero(nf.any(1))[0], np.nonzero(nf.any(0))[0]
     assert rows_f.min() == rows_e.min() and rows_f.max() == rows_e.max()  # vertical windows are exact in both modes
     assert cols_f.min() >= cols_e.min() - 3 and cols_f.max() <= cols_e.max() + 3, (cols_e, cols_f)
+
+
+def test_wide_windows_take_the_fused_uint8_kernel(aa, golden_kat):
+    """test.py's own thumbnail sizes (test.py:15-21: (120, 96) -> 17 bilinear / 33 bicubic taps along W) and other strong down-scales:
+    uint8 in Pillow arithmetic now runs the fused single-launch kernel with a 24- or 34-tap window (up to 6 open output rows), for
+    channels_last and planar bytes: bit-identical to Pillow (oracle) and to the generic two-launch path."""
+    from interpolate_antialiasing_amd import _lib
+
+    rgb = golden_kat["rgb"]  # the reference's test.png, 438 x 906 x 3
+    x_hwc = torch.from_numpy(np.ascontiguousarray(rgb)).cuda()[None].repeat(3, 1, 1, 1)
+    x_hwc[1] = torch.flip(x_hwc[1], dims=(1,))
+    x_hwc[2] = torch.randint(0, 256, x_hwc[2].shape, dtype=torch.uint8, device="cuda")
+    for filt in ("linear", "cubic"):
+        for size in ((96, 120), (60, 200), (30, 115), (200, 130)):
+            for planar in (False, True):
+                x = x_hwc.permute(0, 3, 1, 2)
+                x = x.contiguous() if planar else x
+                try:
+                    _lib.set_fused(1)
+                    y1 = _fn(aa, filt)(x, list(size))
+                    v1 = _lib.last_variant()
+                    _lib.set_fused(0)
+                    y0 = _fn(aa, filt)(x, list(size))
+                finally:
+                    _lib.set_fused(1)
+                assert v1 == ("fused_u8_planar_pil_v3" if planar else "fused_u8_nhwc_pil_v3"), (v1, filt, size, planar)
+                assert torch.equal(y1, y0), (filt, size, planar)
+                exp = oracle.pil_resize_u8(filt, x.cpu().numpy(), size)
+                assert np.array_equal(y1.cpu().numpy(), exp), (filt, size, planar)
+    # beyond 34 taps (or more than 6 open rows): still the generic path
+    y = aa.cubic_forward(x_hwc.permute(0, 3, 1, 2), [40, 40])
+    assert _lib.last_variant().startswith("generic"), _lib.last_variant()
+    assert np.array_equal(y.cpu().numpy(), oracle.pil_resize_u8("cubic", x_hwc.permute(0, 3, 1, 2).cpu().numpy(), (40, 40)))
 
 
 def test_strided_views_are_read_in_place(aa, monkeypatch):
