@@ -149,6 +149,9 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   constexpr int EPQ = 16 / ES;              // elements per aligned 16-byte read
   constexpr int TWP = EPQ * NQ;
   constexpr int TW = CS == 1 ? TWP - (EPQ - 1) : TWP;  // taps a lane can hold
+  // more than 28 window positions: their lane masks no longer fit the scalar registers (two per position), so the AND form is used —
+  // one 0 / ~0 VECTOR register per position (see sub_masked)
+  constexpr bool ANDM = AA_F32_ANDMASK != 0 || TWP > 28;
   static_assert(CS == 1 || DT == AA_F32, "interleaved channels: fp32 only");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
@@ -206,7 +209,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
     const bool mine = j >= 0 && j < xs;
     wreg[q] = (mine && j < p.ksize_w) ? kw[(size_t)ox * p.ksize_w + j] : (real)0;
     inwin[q] = __ballot(mine);
-    if (AA_F32_ANDMASK) wreg[q] = -wreg[q];  // (the product is subtracted, see sub_masked)
+    if (ANDM && !AA_F32_FAST) wreg[q] = -wreg[q];  // (the product is subtracted, see sub_masked)
     mk[q] = mine ? 0xFFFFFFFFu : 0u;
     asm volatile("" : "+v"(mk[q]));  // (a plain register to the compiler: or it turns the AND back into a v_cndmask on a lane mask)
   }
@@ -318,7 +321,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
         continue;
       }
       const real prod = dq * wreg[q];
-      if constexpr (AA_F32_ANDMASK != 0) {
+      if constexpr (ANDM) {
         acc = sub_masked(acc, prod, mk[q]);
       } else {
         const real sum = acc + prod;
@@ -485,7 +488,7 @@ int quads_for(int taps, int epq) {
     return 0;
   }
   if (epq == 4) {
-    const int opts[] = {2, 3, 4, 5, 7};
+    const int opts[] = {2, 3, 4, 5, 7, 9};  // (9: 33 taps — test.py's bicubic 906 -> 120 thumbnails)
     for (int o : opts)
       if (taps <= 4 * o - 3) return o;
     return 0;
@@ -526,6 +529,13 @@ bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw
   // elements a strip's windows cover: the spread of 64 window starts (+EPQ-1: the first one rounded down to the 16-byte
   // grid) + one window; in 16-byte pieces
   g->nseg = (aw.span64p1 + (epq - 1) + epq * g->nq + (epq - 1)) / epq;
+  if (g->nseg > 128 && aw.span4p1 > 0) {  // strong down-scaling: strips of 32 columns (half the lanes idle; such a shape is bound by its input stream)
+    const int by4 = 11 * (aw.span4p1 - 1) + 1;
+    const int span32 = by4 < aw.span64p1 ? by4 : aw.span64p1;
+    g->strip_w = 32;
+    g->nstrips = (int)((oW + 31) / 32);
+    g->nseg = (span32 + (epq - 1) + epq * g->nq + (epq - 1)) / epq;
+  }
   return g->nseg <= 128;
 }
 
@@ -594,7 +604,8 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
       case 3: rc = launch_q<3, AA_F32>(mc, p, q); break;
       case 4: rc = launch_q<4, AA_F32>(mc, p, q); break;
       case 5: rc = launch_q<5, AA_F32>(mc, p, q); break;
-      default: rc = launch_q<7, AA_F32>(mc, p, q); break;
+      case 7: rc = launch_q<7, AA_F32>(mc, p, q); break;
+      default: rc = launch_q<9, AA_F32>(mc, p, q); break;
     }
 #if !AA_F32_FAST
   } else if (q.dtype == AA_F64) {

@@ -1222,6 +1222,15 @@ def test_wide_windows_take_the_fused_uint8_kernel(aa, golden_kat):
                 assert torch.equal(y1, y0), (filt, size, planar)
                 exp = oracle.pil_resize_u8(filt, x.cpu().numpy(), size)
                 assert np.array_equal(y1.cpu().numpy(), exp), (filt, size, planar)
+    # fp32 planes: 33-tap windows (9 aligned reads per row, lane masks in vector registers) on strips of 32 columns
+    xf = x_hwc.permute(0, 3, 1, 2).float().contiguous()
+    for filt, size in (("cubic", (96, 120)), ("cubic", (200, 130)), ("linear", (60, 110))):
+        y = _fn(aa, filt)(xf, list(size))
+        assert _lib.last_variant() == "fused_f32_nchw", (_lib.last_variant(), filt, size)
+        assert np.array_equal(y.cpu().numpy(), oracle.forward(filt, xf.cpu().numpy(), size, nthreads=8)), (filt, size)
+        yf = _fn(aa, filt)(xf, list(size), precision="fast")
+        assert _lib.last_variant() == "fused_f32_nchw_fast"
+        np.testing.assert_allclose(yf.cpu().numpy(), y.cpu().numpy(), rtol=1e-4, atol=1e-4 * 255)
     # beyond 34 taps (or more than 6 open rows): still the generic path
     y = aa.cubic_forward(x_hwc.permute(0, 3, 1, 2), [40, 40])
     assert _lib.last_variant().startswith("generic"), _lib.last_variant()
