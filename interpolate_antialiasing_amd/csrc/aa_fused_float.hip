@@ -221,10 +221,13 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
 
   const unsigned long long plane_off = (unsigned long long)plane * p.plane_in_bytes;
   unsigned long long remaining = p.total_in_bytes - plane_off;
-  // the range check works per dword and rows of 16-bit elements may start on odd halves: serve the tensor's last element
-  // even when its dword straddles the end (the two bytes beyond are never used: positions outside a lane's taps are skipped)
-  if (ES == 2) remaining += 2;
+  // The range check works per dword, and rows of 16-bit elements with an odd W start on odd halves: in the LAST row of the LAST
+  // plane the dword holding the tensor's final element then straddles the end of the tensor and is refused (zeros).  It must be:
+  // extending the range by the two bytes beyond lets the load touch memory that is not the tensor's, and when the tensor ends on
+  // the last byte of a mapped page that is a memory fault (seen once in 90 000 fuzz problems: a bf16 tensor of 19 x 512 bytes at
+  // the end of an allocator block).  The final element is fetched on its own instead (patch_last below).
   if (remaining > 0xFFFFFFFCull) remaining = 0xFFFFFFFCull;
+  const int fix_row = (ES == 2 && (p.Wp & 1) && (long long)plane + 1 == p.n_groups / p.ybands) ? p.H - 1 : -1;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)in + plane_off), 0, (unsigned)remaining, 0x00020000);
   const unsigned row_bytes = p.row_pitch;
@@ -354,6 +357,19 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
     }
   };
 
+  // 16-bit elements, odd W: the staged image of the tensor's very last row lacks its final element (see fix_row); lane 0 reads
+  // that element with an ordinary 2-byte load and puts it (and a zero for the position beyond the row) into the slot
+  auto patch_last = [&](int slot) {
+    const int pos = p.Wp - 1 - seg0;  // position inside the strip's segment (even: seg0 is a multiple of 8, W is odd)
+    if (pos < 0 || pos >= p.nseg * EPQ) return;
+    if (lane == 0) {
+      const unsigned short v = *(const unsigned short *)((const uint8_t *)in + plane_off + (unsigned long long)(p.H - 1) * row_bytes +
+                                                         (unsigned long long)(p.Wp - 1) * 2u);
+      *(unsigned *)(lds + lds_base + slot * p.seg_bytes + pos * 2) = (unsigned)v;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  };
+
   for (int i = 0; i < G; i++)
     if (i < n_rows) dma(a + (unsigned)i * row_bytes, i);
   int r = r_begin;
@@ -377,6 +393,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
         int younger = n_rows - 1 - x;
         younger = younger < G - 1 ? younger : G - 1;
         wait_vmcnt_f(younger * NDMA);
+        if (ES == 2 && r == fix_row) patch_last(i);  // (the band's last row: never inside the unrolled groups above)
         const Scatter sc = load_scatter(r);
         row_step(i, sc);
         if (x + G < n_rows) dma(a + (unsigned)G * row_bytes, i);

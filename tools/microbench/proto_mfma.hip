@@ -115,7 +115,8 @@ int main(int argc, char **argv) {
   p.plan_bytes = (unsigned)g.total;
   p.in_mis = 0;
   p.img_in_bytes = (unsigned long long)H * W * C; p.img_out_bytes = (unsigned long long)oH * oW * C;
-  p.total_in_bytes = in_bytes + 3;  // (unaligned dwords: the one holding the last byte may end 3 bytes later)
+  p.total_in_bytes = in_bytes + 3;  // (unaligned dwords: the one holding the last byte may end 3 bytes later.  PROTOTYPE ONLY: the buffer below is
+                                  //  allocated 256 bytes longer; a shipped kernel must not read past a tensor - see patch_last in aa_fused_float.hip)
   p.total_out_bytes = out_bytes; p.n_images = N;
   p.x4 = (((uintptr_t)out & 15) == 0 && (oW * C) % 16 == 0 && (oH * oW * C) % 16 == 0) ? 1 : 0;
   constexpr int R = PROTO_R;
