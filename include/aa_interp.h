@@ -151,9 +151,10 @@ int aa_table_transpose(const void *table_dev, void *tr_table_dev, size_t tr_tabl
  * per-call path). */
 int aa_table_query(const void *table_dev, aa_table_header *host_header, aa_stream_t stream);
 
-/* Workspace (bytes) the forward needs for this problem; 0 when a fused single-launch path applies.  The answer assumes
- * the image pointers handed to aa_resample_fwd are at least 4-byte aligned (any allocator's are); a caller that passes
- * odd pointers should size the workspace with aa_set_fused(0) in effect. */
+/* Workspace (bytes) the forward needs for this problem; 0 when a fused single-launch path applies.  The answer depends on the
+ * shape and the tables only, never on the pointers: which kernel runs is decided from the same facts, and a uint8 view that starts
+ * on an odd byte is served by the same kernels (byte stores instead of dword stores).  Tensors of 2 / 4 / 8-byte elements must
+ * start on an element boundary (AA_ERR_BAD_SHAPE otherwise). */
 size_t aa_workspace_bytes(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, int64_t oH, int64_t oW,
                           const aa_axis *ax_h, const aa_axis *ax_w);
 

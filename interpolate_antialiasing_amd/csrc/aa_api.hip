@@ -267,6 +267,11 @@ static int resample_fwd_impl(const void *in_dev, void *out_dev, void *workspace_
     return AA_OK;
   }
   if (!in_dev || !out_dev) return AA_ERR_NULL;
+  {  // a tensor of 2 / 4 / 8-byte elements starts on an element boundary; anything else is not a tensor (and the kernels' dispatch must
+     // not depend on the pointers: aa_workspace_bytes answers from the shape alone)
+    const uintptr_t es = dtype == AA_U8 ? 1 : (dtype == AA_F64 ? 8 : (dtype == AA_F32 ? 4 : 2));
+    if ((((uintptr_t)in_dev | (uintptr_t)out_dev) & (es - 1)) != 0) return AA_ERR_BAD_SHAPE;
+  }
 
   AAProblem p;
   p.in = in_dev; p.out = out_dev; p.ws = workspace_dev; p.ws_bytes = workspace_bytes;

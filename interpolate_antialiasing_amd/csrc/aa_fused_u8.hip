@@ -44,6 +44,7 @@ struct FusedU8Params {
   unsigned ring_magic;  // floor(2^32 / ring_rows) + 1: slot(r) = r - ring_rows * mulhi(r, magic), exact for r < 2^20
   int pitch;      // LDS bytes per ring row (multiple of 16)
   unsigned long long img_in_bytes, img_out_bytes, total_in_bytes;
+  int byte_store;  // the output pointer is not dword aligned (a sliced view): four byte stores per lane instead of one dword
 };
 
 template <int NDW>
@@ -226,7 +227,13 @@ fused_u8_nhwc_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, 
           a3 += (int)(dw >> 24) * w;
         }
         const unsigned o = pack4_clip8(a0, a1, a2, a3);
-        out_img[(((size_t)oy * p.oW + ox0) * C) >> 2] = o;
+        unsigned *const dst = out_img + ((((size_t)oy * p.oW + ox0) * C) >> 2);
+        if (p.byte_store) {  // (wave-uniform)
+          uint8_t *const db = (uint8_t *)dst;
+          db[0] = (uint8_t)o; db[1] = (uint8_t)(o >> 8); db[2] = (uint8_t)(o >> 16); db[3] = (uint8_t)(o >> 24);
+        } else {
+          *dst = o;
+        }
       }
     }
     // no second barrier: the next chunk's horizontal pass writes rows >= r_end, whose ring slots cannot alias the
@@ -313,7 +320,6 @@ bool aa_fused_u8_nhwc_applicable(int dtype, int layout, int64_t N, int64_t C, in
 
 int aa_try_fused_u8_nhwc(const AAProblem &q, const char **variant) {
   if (!aa_fused_u8_nhwc_applicable(q.dtype, q.layout, q.N, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
-  if (((uintptr_t)q.out & 3) != 0) return 0;
   const int C = (int)q.C;
   const int taps_w = q.aw.max_taps > 0 ? q.aw.max_taps : q.aw.ksize;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
@@ -329,6 +335,7 @@ int aa_try_fused_u8_nhwc(const AAProblem &q, const char **variant) {
   p.img_in_bytes = (unsigned long long)q.H * q.W * C;
   p.img_out_bytes = (unsigned long long)q.oH * q.oW * C;
   p.total_in_bytes = p.img_in_bytes * (unsigned long long)q.N;
+  p.byte_store = ((uintptr_t)q.out & 3) != 0 ? 1 : 0;  // (no pointer-dependent decline: aa_workspace_bytes answered 0 from the shape alone)
 
   int xbands, bw, ring_rows, pitch;
   v1_geometry(q.C, q.H, q.oW, q.ah, &xbands, &bw, &ring_rows, &pitch);

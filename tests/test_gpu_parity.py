@@ -424,6 +424,44 @@ def test_all_fused_generations_agree(aa):
     assert seen == ["fused_u8_nhwc_pil_v3", "fused_u8_nhwc_pil"], seen
 
 
+def test_dispatch_does_not_depend_on_pointers(aa):
+    """aa_workspace_bytes() answers from the shape alone, so no kernel may decline on a pointer: a uint8 output that starts on an odd byte
+    (a sliced view handed to the C-ABI) is served by the same fused kernels with byte stores — both uint8 generations — and a float
+    tensor that does not start on an element boundary is an error, not a silent change of path."""
+    import ctypes
+
+    from interpolate_antialiasing_amd import _lib, tables
+
+    L = _lib.load()
+    torch.manual_seed(21)
+    x = torch.randint(0, 256, (3, 438, 906, 3), dtype=torch.uint8, device="cuda")  # NHWC bytes
+    th = tables.get_table(_lib.FILTER_LINEAR, _lib.TABLE_PIL, 438, 196, False, 0.0, x.device)
+    tw = tables.get_table(_lib.FILTER_LINEAR, _lib.TABLE_PIL, 906, 320, False, 0.0, x.device)
+    ah, aw = th.axis(), tw.axis()
+    assert L.aa_workspace_bytes(_lib.U8, _lib.NHWC, 3, 3, 438, 906, 196, 320, ctypes.byref(ah), ctypes.byref(aw)) == 0
+    ref = aa.linear_forward(x.permute(0, 3, 1, 2), [196, 320]).permute(0, 2, 3, 1).contiguous()
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for mode, want in ((1, "fused_u8_nhwc_pil_v3"), (2, "fused_u8_nhwc_pil")):
+            _lib.set_fused(mode)
+            for off in (1, 2, 3):
+                buf = torch.zeros(ref.numel() + 8, dtype=torch.uint8, device="cuda")
+                rc = L.aa_resample_fwd_ex(x.data_ptr(), buf.data_ptr() + off, None, 0, _lib.U8, _lib.NHWC, 3, 3, 438, 906,
+                                          ctypes.byref(ah), ctypes.byref(aw), 0, stream)
+                assert rc == 0, (mode, off, rc)
+                assert _lib.last_variant() == want
+                assert torch.equal(buf[off:off + ref.numel()], ref.reshape(-1)), (mode, off)
+                assert int(buf[:off].sum()) == 0 and int(buf[off + ref.numel():].sum()) == 0  # nothing written outside the tensor
+    finally:
+        _lib.set_fused(1)
+    xf = torch.rand(1, 1, 64, 64, device="cuda")
+    tf = tables.get_table(_lib.FILTER_LINEAR, _lib.TABLE_F32, 64, 32, False, 0.0, xf.device)
+    af = tf.axis()
+    out = torch.empty(32 * 32 + 4, device="cuda")
+    rc = L.aa_resample_fwd_ex(xf.data_ptr(), out.data_ptr() + 2, None, 0, _lib.F32, _lib.NCHW, 1, 1, 64, 64, ctypes.byref(af), ctypes.byref(af), 0, stream)
+    assert rc == -4, rc  # AA_ERR_BAD_SHAPE
+
+
 def test_nonfinite_inputs_do_not_leak(aa):
     """fp32: a NaN/inf pixel may only reach the outputs whose window really holds it (zero-padded taps are not summed)."""
     x = torch.rand(1, 1, 64, 128, device="cuda")
