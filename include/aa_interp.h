@@ -251,6 +251,11 @@ int aa_set_fused(int enabled);
  * The library reads NO environment variables (developer builds with -DAA_V2_TUNING do, for experiments). */
 int aa_set_store_form(int form);
 
+/* Plane groups of the fused uint8 kernel, process-wide; returns the previous setting.  1 (default): planar (NCHW) uint8 images of
+ * three channels run the three planes of an image in one wave (Pillow arithmetic, shrinking heights); 0: one wave per plane, as every
+ * other planar shape does.  Same results either way — a test hook and the A/B switch of the measurements in DESIGN.md. */
+int aa_set_plane_groups(int enabled);
+
 /* Name of the kernel variant the last aa_resample_fwd on this thread dispatched to (for tests/bench). */
 const char *aa_last_variant(void);
 

@@ -29,7 +29,7 @@ EXPORTS = (
     "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build_bytes", "aa_table_build",
     "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_workspace_bytes", "aa_resample_fwd",
     "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_resample_axis_fwd", "aa_set_fused",
-    "aa_last_variant", "aa_probe_copy", "aa_workspace_bytes_u8_to_f32", "aa_resample_fwd_u8_to_f32", "aa_set_store_form", "aa_resample_fwd_ex", "aa_resample_fwd_strided",
+    "aa_last_variant", "aa_probe_copy", "aa_workspace_bytes_u8_to_f32", "aa_resample_fwd_u8_to_f32", "aa_set_store_form", "aa_set_plane_groups", "aa_resample_fwd_ex", "aa_resample_fwd_strided",
 )
 
 
@@ -123,6 +123,8 @@ def load() -> ctypes.CDLL:
     L.aa_set_fused.restype = i32
     L.aa_set_store_form.argtypes = [i32]
     L.aa_set_store_form.restype = i32
+    L.aa_set_plane_groups.argtypes = [i32]
+    L.aa_set_plane_groups.restype = i32
     if L.aa_abi_version() != 3:
         raise AAInterpError("libaa_interp.so ABI version mismatch")
     _lib = L
@@ -156,6 +158,12 @@ def set_store_form(form: int) -> int:
     return int(load().aa_set_store_form(int(form)))
 
 
+def set_plane_groups(enabled: int) -> int:
+    """Test / A-B hook: 1 (default) planar three-channel uint8 images run all three planes in one wave, 0 one wave per plane; returns the
+    previous setting."""
+    return int(load().aa_set_plane_groups(int(enabled)))
+
+
 def last_variant() -> str:
     return load().aa_last_variant().decode()
 
@@ -165,6 +173,7 @@ def last_variant() -> str:
 KERNEL_SOURCES = {
     "fused_u8_nhwc_pil_v3": ("aa_fused_u8_v3_impl.h", "aa_fused_u8_v3.hip", "aa_fused_u8_v3_c3.hip", "aa_common.h"),
     "fused_u8_nhwc_pil": ("aa_fused_u8.hip", "aa_common.h"),
+    "fused_u8_planar_pil_v3": ("aa_fused_u8_v3_impl.h", "aa_fused_u8_v3.hip", "aa_fused_u8_v3_c3g.hip", "aa_fused_u8_v3_c1.hip", "aa_common.h"),
 }
 
 

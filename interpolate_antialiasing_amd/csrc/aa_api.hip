@@ -7,6 +7,7 @@
 #include "aa_common.h"
 
 int g_aa_store_form = -1;  // (aa_common.h; read by aa_fused_float_up.hip)
+int g_aa_plane_groups = 1;  // (aa_common.h; read by aa_fused_u8_v3.hip)
 
 namespace {
 
@@ -444,6 +445,12 @@ int aa_set_fused(int enabled) {
 int aa_set_store_form(int form) {
   const int prev = g_aa_store_form;
   g_aa_store_form = (form < -1 || form > 1) ? -1 : form;
+  return prev;
+}
+
+int aa_set_plane_groups(int enabled) {
+  const int prev = g_aa_plane_groups;
+  g_aa_plane_groups = enabled ? 1 : 0;
   return prev;
 }
 

@@ -59,6 +59,8 @@ inline const char *aa_knob(const char *) { return nullptr; }
 // store form of the up-scaling / backward kernel, set through aa_set_store_form() (tests force the streaming forms at small sizes):
 // -1 automatic (by output size), 0 never streaming, 1 always streaming
 extern int g_aa_store_form;
+// plane groups of the fused uint8 kernel (aa_set_plane_groups): 1 = planar three-channel images run all three planes in one wave
+extern int g_aa_plane_groups;
 
 // ---- launch-error plumbing -------------------------------------------------------------------------------
 #define AA_HIP_CHECK_LAUNCH()                 \

@@ -120,6 +120,25 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   if (lds > 64 * 1024) return 0;
 
   p.ybands = 1;
+  p.plane_in_bytes = p.plane_out_bytes = 0;
+
+  // Plane groups (template parameter PL of the kernel): planar images of three channels, Pillow arithmetic, shrinking heights — one wave
+  // filters the same strip and band of all three planes, sharing each row's fixed work.  The single-plane form keeps every other planar
+  // shape (1, 2, 4+ channels, growing heights, float arithmetic, three segments beyond one staging DMA, windows beyond 16 taps).
+  if (planar && q.C == 3 && !flt && !up && tw <= 16 && tw >= 4 && p.nseg <= 21 && G == 8 && q.ah.scatter_max <= 4 &&
+      3 * p.img_in_bytes <= 0x7FFFFFF0ull && 3 * p.img_out_bytes <= 0x7FFFFFF0ull && g_aa_plane_groups != 0) {
+    FusedU8V3Params pg = p;
+    pg.plane_in_bytes = p.img_in_bytes;    // (the single-plane form's "images" are the planes)
+    pg.plane_out_bytes = p.img_out_bytes;
+    pg.img_in_bytes = 3 * p.img_in_bytes;
+    pg.img_out_bytes = 3 * p.img_out_bytes;
+    pg.n_images = q.N;
+    const int rcg = aa_v3_launch_c3g(tw, q.ah.scatter_max, pg, q, (size_t)G * 1024);  // (a 1-KiB stage slot per row: the kernel's fixed layout)
+    if (rcg != 0) {
+      if (rcg == 1) *variant = "fused_u8_planar_pil_v3";
+      return rcg;
+    }
+  }
 
   int rc;
   if (up) {

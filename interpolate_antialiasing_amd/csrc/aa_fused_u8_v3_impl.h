@@ -97,6 +97,8 @@ struct FusedU8V3Params {
   int fast;        // AA_FLAG_FAST on a float-arithmetic problem: the FMA instantiations (aa_fused_u8_v3_c{1,3,4}ff.hip)
   int byte_store;  // output rows that are not whole dwords (oW*C % 4 != 0, or C == 3 with oW % 4 != 0) or an output pointer that
                    // is not dword aligned: every lane stores its own bytes instead of the quad-merged dword stores
+  // plane-group kernels (template parameter PL): bytes between the channel planes of one image, input and output
+  unsigned long long plane_in_bytes, plane_out_bytes;
 };
 
 namespace {
@@ -157,12 +159,33 @@ __device__ inline void wait_vmcnt(int n) {  // rounding n DOWN only waits longer
 //      ends at the row just filtered is the weighted sum of the ring's last `ysize` entries (weights: one scalar load of the H
 //      table's gather record, taps in order).  The row pipeline is the generic-address one; DMA completion is tracked per stage
 //      slot because the output stores (several per input row) share the in-order vmcnt counter with the DMAs.
-template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0>
+// PL: plane groups — planar (NCHW) images of PL = C channel planes: one wave filters the same strip and band of ALL the image's planes,
+//     row by row.  The single-plane form (C = 1, one wave per plane) spends as much on a row's fixed work — scatter record, waits, loop,
+//     window addressing: the scalar unit is 0.81 busy beside a 0.85 busy vector ALU (r02_pmc_u8_planar.json) — as on its 6 multiplies;
+//     here that work is shared by the planes.  What bounds the single-plane form, though, is the vector memory unit's ADDRESS path: a
+//     staging DMA costs it the same whether 10 of its lanes fetch or 64, and planar rows need one per plane and strip
+//     (SQ_VMEM_TA_ADDR_FIFO_FULL: 2 cycles for every cycle the unit works, r03_pmc_u8_planar_groups.json).  So ONE DMA per row stages
+//     the segments of all PL planes (lane = plane * nseg + piece, PL * nseg <= 64).  The planes' segments start on different 16-byte
+//     phases, so the DMA reads from each segment's exact first byte (LDS-DMA serves any source alignment): every staged image then
+//     starts at LDS phase 0 and the window addresses are per-slot constants.  Price of unaligned dwords: the range check refuses a
+//     dword that straddles the end of the tensor, so the last 3 bytes of the tensor's very last row are fetched on their own
+//     (pl_patch_last; nothing is ever read past the tensor).  One single-channel window per plane, the same weights for all of them;
+//     vertical pass and accumulators as for C interleaved channels; one 64-byte row piece stored per plane.  Pillow arithmetic,
+//     shrinking heights.
+template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0, int PL = 0>
 __global__ void __launch_bounds__(512) AA_V3_OCC
 fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const char *__restrict__ tab_w,
                         const char *__restrict__ tab_h, const FusedU8V3Params p) {
-  constexpr int NV = (C * TW + 3) / 4;  // dwords holding one window
-  constexpr int ND = NV + 1;            // aligned dwords fetched per window
+  static_assert(PL == 0 || (PL == C && !PERIODIC && !FLT && UPK == 0 && !TWO_DMA), "plane groups: Pillow arithmetic, shrinking heights, generic addressing");
+  constexpr int PLN = PL > 0 ? PL : 1;  // windows per lane and row
+  constexpr int CB = PL > 0 ? 1 : C;    // bytes per pixel in a staged row
+  constexpr int NV1 = (CB * TW + 3) / 4;  // dwords holding one window
+  constexpr int ND1 = NV1 + 1;            // aligned dwords fetched per window
+  constexpr int NV = PLN * NV1, ND = PLN * ND1;
+  struct SA { unsigned s[PLN]; };  // LDS byte address of each window of a row (its low two bits: the realignment shift)
+  // plane groups: FIXED stage layout — a slot is 1024 bytes (one DMA: 64 lanes x 16 B), plane c's segment starts at c * 336 (21 pieces
+  // per plane, PL * 21 <= 64), so every window read is the lane's constant base + an immediate offset: no address arithmetic per row
+  constexpr int PL_SLOT = 1024, PL_PIECES = 21, PL_PLANE = PL_PIECES * 16;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
   // a workgroup is the nstrips_blk independent waves (strips) of one band: no barrier, no shared LDS; they only
@@ -221,20 +244,29 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     wreg[j] = FLT ? w : (w << 8) >> 8;  // 24-bit operand for v_mul_i32_i24 (FLT: the float's bit pattern, 0 = +0.0f)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // table loads done: from here on vmcnt counts DMAs and stores
-  const int seg_first = __builtin_amdgcn_readfirstlane(start * C);  // lane 0 is always active
-  const int c_l = start * C - seg_first;                            // window offset inside the segment (bytes)
+  const int seg_first = __builtin_amdgcn_readfirstlane(start * CB);  // lane 0 is always active
+  const int c_l = start * CB - seg_first;                            // window offset inside the segment (bytes)
 
   const unsigned long long img_off = (unsigned long long)p.in_mis + (unsigned long long)n * p.img_in_bytes;
   const unsigned long long base_off = img_off & ~15ull;
   unsigned long long remaining = p.total_in_bytes - base_off;
-  remaining = (remaining + 3ull) & ~3ull;  // the range check works per dword: serve the last, partial one too
+  // the range check works per dword: serve the last, partial one too — an ALIGNED dword, it cannot leave the tensor's last page.  (Plane
+  // groups read unaligned dwords: exact range, see pl_patch_last.)
+  if constexpr (PL == 0) remaining = (remaining + 3ull) & ~3ull;
   if (remaining > 0xFFFFFFFCull) remaining = 0xFFFFFFFCull;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)(in + base_off), 0, (unsigned)remaining, 0x00020000);
   const unsigned row_bytes = p.row_pitch;
-  const int lds_base = wv * G * p.seg_bytes;  // this wave's private stage ring
+  const int lds_base = PL > 0 ? wv * G * PL_SLOT : wv * G * p.seg_bytes;  // this wave's private stage ring
   const unsigned lane_lds = (unsigned)(lds_base + c_l);
-  const bool dma_lane0 = lane < p.nseg;
+  unsigned pl_voff = 0;  // plane groups: staging lane = plane * 21 + piece
+  bool pl_dma_lane = false;
+  if constexpr (PL > 0) {
+    const int pc = lane / PL_PIECES, piece = lane - pc * PL_PIECES;
+    pl_voff = (unsigned)pc * (unsigned)p.plane_in_bytes + (unsigned)piece * 16u;
+    pl_dma_lane = pc < PL && piece < p.nseg;
+  }
+  const bool dma_lane0 = PL > 0 ? pl_dma_lane : lane < p.nseg;
   const bool dma_lane1 = lane + 64 < p.nseg;
   constexpr int dma_per_row = TWO_DMA ? 2 : 1;
   const unsigned voff = (unsigned)lane * 16u;
@@ -244,7 +276,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   unsigned long long out_rem = p.total_out_bytes - out_off;
   if (out_rem > 0xFFFFFFFFull) out_rem = 0xFFFFFFFFull;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(out + out_off), 0, (unsigned)out_rem, 0x00020000);
-  const unsigned out_row_bytes = (unsigned)p.oW * C;
+  const unsigned out_row_bytes = (unsigned)p.oW * CB;
   float nm_mean[C], nm_std[C];  // (float output with normalisation only)
 #pragma unroll
   for (int c = 0; c < C; c++) {
@@ -255,7 +287,11 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   unsigned store_voff;
   bool store_lane;
   unsigned perm_sel = 0;
-  if constexpr (C == 3) {
+  if constexpr (PL > 0) {
+    // plane groups: per plane, a quad of lanes holds 4 consecutive bytes = 1 dword, stored by the quad's first lane
+    store_voff = (unsigned)(ox0 + lane);
+    store_lane = ((lane & 3) == 0) && ((lane | 3) < bw);
+  } else if constexpr (C == 3) {
     // a quad of lanes holds 4 pixels = 12 bytes = 3 dwords; quad lanes 0..2 each assemble and store one of them
     const int q = lane & 3;
     store_voff = (unsigned)(ox0 * 3 + (lane >> 2) * 12 + q * 4);
@@ -299,7 +335,12 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     }
     if (AA_V3_PRIO) __builtin_amdgcn_s_setprio(3);
     const unsigned soff = AA_V3_ABL == 7 ? (a_row & 0x3F0u) : (a_row & ~15u);  // 7: every DMA hits the same 1.6 KB
-    const int dst = lds_base + slot * p.seg_bytes;
+    const int dst = lds_base + slot * (PL > 0 ? PL_SLOT : p.seg_bytes);
+    if constexpr (PL > 0) {  // ONE DMA for the row's PL segments, each from its exact first byte; side by side in the slot
+      if (dma_lane0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, pl_voff, a_row, 0, AA_V3_AUX);
+      if (AA_V3_PRIO) __builtin_amdgcn_s_setprio(0);
+      return;
+    }
     if (dma_lane0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + dst), 16, voff, soff, 0, AA_V3_AUX);
     if constexpr (TWO_DMA) {
       if (dma_lane1)
@@ -316,9 +357,20 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     slot_ph[j] = (unsigned)(j * p.seg_bytes) + ph;  // uniform
     slot_ra[j] = (lane_lds + slot_ph[j]) & ~3u;      // per lane
   }
-  auto fetch = [&](unsigned a_row, int slot, unsigned (&d)[ND], bool tables = true) -> unsigned {
+  auto fetch = [&](unsigned a_row, int slot, unsigned (&d)[ND], bool tables = true) -> SA {
+    SA r;
     unsigned sa, ra;
-    if (AA_V3_ABL == 6) return 0;
+    if (AA_V3_ABL == 6) { for (int c = 0; c < PLN; c++) r.s[c] = 0; return r; }
+    if constexpr (PL > 0) {  // (every staged segment starts at phase 0 of its fixed place: constant base, immediate offsets)
+      const __attribute__((address_space(3))) unsigned *al = (const __attribute__((address_space(3))) unsigned *)(uintptr_t)(lane_lds & ~3u);
+#pragma unroll
+      for (int c = 0; c < PL; c++) {
+#pragma unroll
+        for (int k = 0; k < ND1; k++) d[c * ND1 + k] = al[(slot * PL_SLOT + c * PL_PLANE) / 4 + k];
+        r.s[c] = lane_lds;
+      }
+      return r;
+    }
     if (PERIODIC && tables) {  // `slot` must be a compile-time constant here (register arrays)
       sa = lane_lds + slot_ph[slot];  // only its low two bits are used (v_alignbyte)
       ra = slot_ra[slot];
@@ -332,12 +384,14 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
 #pragma unroll
       for (int k = 0; k < NV; k++) d[k] = ul[k];
       d[ND - 1] = 0;
-      return sa;
+      r.s[0] = sa;
+      return r;
     }
     const __attribute__((address_space(3))) unsigned *al = (const __attribute__((address_space(3))) unsigned *)(uintptr_t)ra;
 #pragma unroll
     for (int k = 0; k < ND; k++) d[k] = al[k];
-    return sa;
+    r.s[0] = sa;
+    return r;
   };
   // scatter record of an input row: first output it feeds, and its weight in that output and the next MAXC-1
   struct Scatter { int first; int cc; int w[MAXC]; };  // raw record words (nothing depends on them until they are used)
@@ -403,19 +457,35 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));  // keep this rare path's address arithmetic INSIDE it: hoisted out of the row loop it
                                         // costs the common path 5 VGPRs, i.e. a wave per SIMD (76 -> 81 registers)
-      const unsigned bv = (unsigned)((ox0 + lane_o) * C);
+      const unsigned bv = (unsigned)((ox0 + lane_o) * CB);
       const bool act = lane_o < bw;
       if constexpr (UPK > 0) vm_issued += C;
 #pragma unroll
       for (int c = 0; c < C; c++) {
         const unsigned b = FLT ? trunc8(A[0][c]) : (unsigned)clip8_int(A[0][c]);
-        if (act) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, bv + c, (unsigned)oy * out_row_bytes, 0);
+        if constexpr (PL > 0) {  // (plane c of the image)
+          if (act) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, bv, (unsigned)c * (unsigned)p.plane_out_bytes + (unsigned)oy * out_row_bytes, 0);
+        } else {
+          if (act) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, bv + c, (unsigned)oy * out_row_bytes, 0);
+        }
       }
     }
     if constexpr (UPK > 0) {
       if (emit_path == 0) vm_issued += 1;  // the dword store below: lane 0 stores whenever the strip holds a whole quad (it does)
     }
     if (emit_path != 0) {
+    } else if constexpr (PL > 0) {
+      // the lane's PL bytes in one register; per plane, the quad's four bytes are merged into its first lane in two steps (pairs, then
+      // the pair of pairs): one DPP move shared by the planes + per plane one byte permute, one DPP move, one byte permute
+      const unsigned t = pack4_clip8(A[0][0], A[0][1], A[0][PL > 2 ? 2 : 1], A[0][PL - 1]);
+      const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xF5 /*quad_perm:[1,1,3,3]*/, 0xF, 0xF, false);
+#pragma unroll
+      for (int c = 0; c < PL; c++) {
+        const unsigned pair = __builtin_amdgcn_perm(nb, t, 0x0c0c0000u | (unsigned)((4 + c) << 8) | (unsigned)c);  // [own c, neighbour c, 0, 0]
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pair, 0xAA /*quad_perm:[2,2,2,2]*/, 0xF, 0xF, false);
+        const unsigned dw = __builtin_amdgcn_perm(hi, pair, 0x05040100u);
+        if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)c * (unsigned)p.plane_out_bytes + (unsigned)oy * out_row_bytes, 0);
+      }
     } else if constexpr (C == 3) {
       const unsigned t = FLT ? (trunc8(A[0][0]) | (trunc8(A[0][1]) << 8) | (trunc8(A[0][2]) << 16))
                              : pack4_clip8(A[0][0], A[0][1], A[0][2], A[0][2]);
@@ -462,9 +532,12 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   int r = r_begin;  // the input row being filtered
   // one input row: horizontal pass from the fetched window, then scatter into the open output rows
   // the window of the CURRENT row, realigned; consumes the LDS reads issued one row earlier
-  auto realign = [&](const unsigned (&d)[ND], unsigned sa, unsigned (&v)[NV]) {
+  auto realign = [&](const unsigned (&d)[ND], const SA &sa, unsigned (&v)[NV]) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = AA_V3_UNALIGNED ? d[k] : __builtin_amdgcn_alignbyte(d[k + 1], d[k], sa);
+    for (int c = 0; c < PLN; c++)
+#pragma unroll
+      for (int k = 0; k < NV1; k++)
+        v[c * NV1 + k] = AA_V3_UNALIGNED ? d[c * ND1 + k] : __builtin_amdgcn_alignbyte(d[c * ND1 + k + 1], d[c * ND1 + k], sa.s[c]);
   };
   // `steady`: every band starts with a few rows that still feed outputs of the previous band (sc.first < o_base: their weights shift by
   // o_base - sc.first sets); once a row has sc.first == o_base that stays so to the band's end (window ends are non-decreasing).  The
@@ -502,7 +575,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       for (int j = 0; j < (AA_V3_ABL == 5 ? 0 : TW); j++) {
 #pragma unroll
         for (int c = 0; c < C; c++) {
-          const int bi = j * C + c;
+          const int bi = PL > 0 ? c * (4 * NV1) + j : j * C + c;  // (plane groups: channel c's own window)
           const int px = (int)((v[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
           acc[c] += px * wreg[j];
         }
@@ -592,15 +665,32 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     }
   };
 
+  // plane groups: the tensor's last 3 bytes (last image, last plane, last row), which the staging DMA's unaligned dwords may have been
+  // refused; lanes 0 .. 2 fetch one byte each and put it into the staged row.  Called after the row's DMA has landed, before its
+  // window reads.
+  const int pl_fix_row = (PL > 0 && (long long)n + 1 == p.n_images) ? p.H - 1 : -1;
+  auto pl_patch_last = [&](int slot) {
+    if constexpr (PL > 0) {
+      const int q = p.W - 3 + lane;          // row position of this lane's byte
+      const int lpos = q - seg_first;         // ... inside the strip's segment
+      if (lane < 3 && q >= 0 && lpos >= 0 && lpos < p.nseg * 16) {
+        const uint8_t b = in[img_off + (unsigned long long)(PL - 1) * p.plane_in_bytes + (unsigned long long)(p.H - 1) * row_bytes + (unsigned)q];
+        lds[lds_base + slot * PL_SLOT + (PL - 1) * PL_PLANE + lpos] = b;
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+  };
+
   // prologue: the first G rows in flight, window reads of row 0 issued
   for (int i = 0; i < G; i++)
     if (i < n_rows) dma(a + (unsigned)i * row_bytes, i);
   unsigned d0[ND], d1[ND];
-  unsigned sa0 = 0, sa1 = 0;
+  SA sa0 = {}, sa1 = {};
   Scatter sc0 = load_scatter(r_begin), sc1 = sc0;
   {
     const int younger = (n_rows < G ? n_rows : G) - 1;
     wait_vmcnt(younger * dma_per_row);
+    if (PL > 0 && r_begin == pl_fix_row) pl_patch_last(0);
     sa0 = fetch(a, 0, d0, false);
   }
   // Invariant at the top of row x (slot x % G): DMAs issued up to row x+G-1; row x's window reads issued into d0 (x
@@ -669,6 +759,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
             younger = younger < G - 2 ? younger : G - 2;
             wait_vmcnt(younger * dma_per_row);
           }
+          if (PL > 0 && r + 1 == pl_fix_row) pl_patch_last((i + 1) % G);  // (never inside the unrolled groups: they end G rows before the band does)
           if ((i & 1) == 0) { sc1 = load_scatter(r + 1); sa1 = fetch(a + row_bytes, (i + 1) % G, d1, false); }
           else { sc0 = load_scatter(r + 1); sa0 = fetch(a + row_bytes, (i + 1) % G, d0, false); }
         }
@@ -715,9 +806,9 @@ int pick_ybands(int64_t items_per_band, double slots, int taps_h, int64_t H, int
   return (int)ybands;
 }
 
-template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0>
+template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0, int PL = 0>
 int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
-  auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC, FLT, UPK>;
+  auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC, FLT, UPK, PL>;
   auto resident = [&](int s) {  // resident workgroups of s strips per CU for this instantiation and this problem's LDS
     int nb = aa_resident_blocks(kern, 64 * s, lds * s);
     if (nb <= 0) nb = 16 / s;
@@ -837,6 +928,24 @@ int dispatch_tw_wide(int tw, int maxc, const FusedU8V3Params &p, const AAProblem
   return 0;
 }
 
+// plane groups (template parameter PL): the three planes of a planar image in one wave; instantiated in aa_fused_u8_v3_c3g.hip
+template <int TW>
+int launch_planes(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  const bool nonneg = q.aw.filter != AA_FILTER_CUBIC && q.ah.filter != AA_FILTER_CUBIC;
+  if (maxc <= 2) return nonneg ? launch_k<3, TW, 8, 2, false, true, false, false, 0, 3>(p, q, lds, 0) : launch_k<3, TW, 8, 2, false, false, false, false, 0, 3>(p, q, lds, 0);
+  if (maxc <= 3) return nonneg ? launch_k<3, TW, 8, 3, false, true, false, false, 0, 3>(p, q, lds, 0) : launch_k<3, TW, 8, 3, false, false, false, false, 0, 3>(p, q, lds, 0);
+  return nonneg ? launch_k<3, TW, 8, 4, false, true, false, false, 0, 3>(p, q, lds, 0) : launch_k<3, TW, 8, 4, false, false, false, false, 0, 3>(p, q, lds, 0);
+}
+inline int dispatch_tw_planes(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  if (maxc > 4) return 0;
+  if (tw <= 4) return launch_planes<4>(maxc, p, q, lds);
+  if (tw <= 6) return launch_planes<6>(maxc, p, q, lds);
+  if (tw <= 8) return launch_planes<8>(maxc, p, q, lds);
+  if (tw <= 12) return launch_planes<12>(maxc, p, q, lds);
+  if (tw <= 16) return launch_planes<16>(maxc, p, q, lds);
+  return 0;
+}
+
 // growing heights (gather-form vertical pass): generic window addressing, one DMA per row, no scatter accumulators.  Ring of 2
 // rows for the triangle / box filters (never negative: the intermediate needs no clamp), of 6 for everything else.
 template <int C, int TW>
@@ -884,6 +993,8 @@ int aa_v3_launch_c4ff(int tw, int maxc, const FusedU8V3Params &p, const AAProble
 int aa_v3_launch_c1w(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c3w(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c4w(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+// plane groups: planar images of three channels (aa_fused_u8_v3_c3g.hip)
+int aa_v3_launch_c3g(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 // growing heights (aa_fused_u8_v3_c{1,3,4}u.hip)
 int aa_v3_launch_up_c1(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_up_c3(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);

@@ -920,6 +920,45 @@ def test_integration_stub_matches_the_shim(aa):
         stub.linear_forward(xf, [4, 4, 4])
 
 
+def test_plane_groups_equal_single_planes(aa):
+    """Planar (NCHW) uint8 images of three channels run their three planes in one wave (template parameter PL of the fused kernel);
+    aa_set_plane_groups(0) restores one wave per plane.  Both forms and the two-launch path must agree bit for bit: ragged widths (byte
+    stores), odd plane sizes (every plane on its own 16-byte phase), negative weights, several strips, a cropped view, and the
+    oracle on a small case."""
+    from interpolate_antialiasing_amd import _lib
+
+    cases = [((5, 3, 90, 438), (40, 196), "linear"), ((2, 3, 131, 307), (37, 101), "linear"), ((3, 3, 70, 301), (20, 133), "cubic"),
+             ((2, 3, 64, 1000), (31, 420), "linear"), ((1, 3, 33, 97), (9, 16), "box"), ((4, 3, 57, 83), (19, 27), "linear")]
+    try:
+        for shape, out, filt in cases:
+            x = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda")
+            fn = _fn(aa, filt)
+            _lib.set_plane_groups(1)
+            y1 = fn(x, list(out))
+            v1 = _lib.last_variant()
+            _lib.set_plane_groups(0)
+            y2 = fn(x, list(out))
+            v2 = _lib.last_variant()
+            _lib.set_fused(0)
+            y0 = fn(x, list(out))
+            _lib.set_fused(1)
+            assert v1 == v2 == "fused_u8_planar_pil_v3", (shape, out, v1, v2)
+            assert torch.equal(y1, y0), (shape, out, filt, "plane groups")
+            assert torch.equal(y2, y0), (shape, out, filt, "single planes")
+        _lib.set_plane_groups(1)
+        x = torch.randint(0, 256, (2, 3, 45, 77), dtype=torch.uint8, device="cuda")
+        y = aa.linear_forward(x, [17, 30])
+        assert np.array_equal(y.cpu().numpy(), oracle.pil_resize_u8("linear", x.cpu().numpy(), (17, 30)))
+        big = torch.randint(0, 256, (4, 3, 80, 330), dtype=torch.uint8, device="cuda")
+        view = big[1:3, :, 5:75, 13:313]
+        yv = aa.linear_forward(view, [30, 132])
+        assert _lib.last_variant() == "fused_u8_planar_pil_v3"
+        assert torch.equal(yv, aa.linear_forward(view.contiguous(), [30, 132]))
+    finally:
+        _lib.set_fused(1)
+        _lib.set_plane_groups(1)
+
+
 def test_sixteen_bit_tensor_ending_on_its_allocation(aa):
     """Rows of 16-bit elements with an odd W: the dword that holds the tensor's final element straddles the end of the tensor.  The
     fused kernel must neither drop that element nor read the two bytes beyond it (round 3: the second form faulted once in 90 000
