@@ -143,21 +143,28 @@ int aa_device_cu_count();
 #include <mutex>
 template <typename K>
 int aa_resident_blocks(K kern, int threads, size_t lds) {
-  struct Entry { int dev, threads; size_t lds; int nb; };
+  // (K is the kernel's function-pointer TYPE, shared by every instantiation of a kernel template: the kernel itself is part of the key.
+  //  Until round 3 it was not, and a kernel could be sized with the register budget of whichever instantiation had asked first with the
+  //  same threads and LDS bytes — found when the plane-group kernels, whose LDS size is fixed, ran 40 % slower after a sibling had run)
+  struct Entry { const void *kern; int dev, threads; size_t lds; int nb; };
+  constexpr int kEntries = 256;
   static std::mutex mu;
-  static Entry cache[32];
-  static int n = 0;
+  static Entry cache[kEntries];
+  static int n = 0, next = 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
+  const void *id = (const void *)kern;
   std::lock_guard<std::mutex> lock(mu);
   for (int i = 0; i < n; i++)
-    if (cache[i].dev == dev && cache[i].threads == threads && cache[i].lds == lds) return cache[i].nb;
+    if (cache[i].kern == id && cache[i].dev == dev && cache[i].threads == threads && cache[i].lds == lds) return cache[i].nb;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb <= 0) {
     (void)hipGetLastError();
     nb = -1;
   }
-  if (n < 32) cache[n++] = Entry{dev, threads, lds, nb};
+  cache[next] = Entry{id, dev, threads, lds, nb};  // (a full cache forgets its oldest entry)
+  next = next + 1 == kEntries ? 0 : next + 1;
+  if (n < kEntries) n++;
   return nb;
 }
 

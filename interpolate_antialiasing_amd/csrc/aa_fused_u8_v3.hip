@@ -123,9 +123,11 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   p.plane_in_bytes = p.plane_out_bytes = 0;
 
   // Plane groups (template parameter PL of the kernel): planar images of three channels, Pillow arithmetic, shrinking heights — one wave
-  // filters the same strip and band of all three planes, sharing each row's fixed work.  The single-plane form keeps every other planar
-  // shape (1, 2, 4+ channels, growing heights, float arithmetic, three segments beyond one staging DMA, windows beyond 16 taps).
-  if (planar && q.C == 3 && !flt && !up && tw <= 16 && tw >= 4 && p.nseg <= 21 && G == 8 && q.ah.scatter_max <= 4 &&
+  // filters the same strip and band of all three planes, sharing each row's staging DMA and fixed work.  The single-plane form keeps every
+  // other planar shape: 1, 2, 4+ channels; growing heights; float arithmetic; windows beyond 12 taps (the 16-tap instantiation needs 147
+  // VGPRs = 3 waves per SIMD); segments beyond 16 pieces (down-scaling by 4 and more: the single planes' staging DMAs are full enough as
+  // they are, measured +4 % at 1024 -> 224).
+  if (planar && q.C == 3 && !flt && !up && tw <= 12 && tw >= 4 && p.nseg <= 16 && G == 8 && q.ah.scatter_max <= 4 &&
       3 * p.img_in_bytes <= 0x7FFFFFF0ull && 3 * p.img_out_bytes <= 0x7FFFFFF0ull && g_aa_plane_groups != 0) {
     FusedU8V3Params pg = p;
     pg.plane_in_bytes = p.img_in_bytes;    // (the single-plane form's "images" are the planes)

@@ -67,6 +67,12 @@ elif name.startswith("bwdw:"):  # bwdw:<W> : the backward of config A with W inp
     wcols = int(name.split(":")[1])
     x = torch.randn(256, 3, 196, 320, device=dev)
     fn = lambda: aa.linear_backward(x, [196, 320], [256, 3, 438, wcols])
+elif name.startswith("planar:"):  # planar:<H>:<W>:<oH>:<oW>:<linear|cubic>:<B>:<plane groups 0|1>   (uint8 NCHW, Pillow arithmetic)
+    _, h, w, oh, ow, filt, b, grp = name.split(":")
+    _lib.set_plane_groups(int(grp))
+    x = torch.randint(0, 256, (int(b), 3, int(h), int(w)), dtype=torch.uint8, device=dev)
+    op = aa.linear_forward if filt == "linear" else aa.cubic_forward
+    fn = lambda: op(x, [int(oh), int(ow)])
 elif name.startswith("custom:"):  # custom:<u8|u8h|f32|f16>:<nchw|nhwc>:<linear|cubic>:<oW>:<oH>:<B>   (input 438x906x3)
     _, dt, lay, filt, ow, oh, b = name.split(":")
     x = torch.randint(0, 256, (int(b), 438, 906, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
