@@ -173,9 +173,17 @@ def secondary_configs(dev, with_atomics=False):
     round's BENCH json carries them: algorithmic GB/s = (input + output bytes) / event time.  Not the headline metric."""
     from interpolate_antialiasing_amd import _lib, extension_interpolate as aa
 
-    def timed(fn, reps=30):
+    def timed(fn, reps=50, warm_seconds=0.1):
+        # Warm-up by TIME, not by count: for the first 40-60 ms of a new heavy workload the chip runs it 10-35 % slower than it then
+        # settles to (per-launch durations of 600 back-to-back launches under rocprofv3: profiles/r03_launch_transient.txt) — 10 warm-up
+        # launches of a 0.3 ms kernel sit inside that transient.  The headline's --prewarm-seconds serves the same purpose.
         for _ in range(10):
             fn()
+        t_end = time.perf_counter() + warm_seconds
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -248,7 +256,6 @@ def secondary_configs(dev, with_atomics=False):
         3 * (438 * 906 + 196 * 320))
     try:  # cold call ("report cold first-call separately"): a shape never seen in this process — both weight tables are
         # built on device (one 64-byte header read-back each), then the kernel runs; wall clock around call + synchronize
-        import time
         colds = []
         for k in range(5):
             xc = torch.randint(0, 256, (1, 430 + k, 900 + k, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
