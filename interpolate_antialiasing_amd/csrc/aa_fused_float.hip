@@ -536,6 +536,14 @@ bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw
     if (spread > aw.span64p1 - 1) spread = aw.span64p1 - 1;
     const int span = (spread + 4 * g->nq) * (int)C + 3 + (int)C;  // elements (+3: segment start rounded down to 4)
     g->nseg = (span + 3) / 4 + 1;
+    if (g->nseg > 128) {  // strong down-scaling (test.py's 906 -> 120 thumbnails): strips of 32 elements, as for planes below
+      const int steps32 = (31 / (int)C + 1 + 2) / 3;
+      int spread32 = steps32 * (aw.span4p1 - 1);
+      if (spread32 > aw.span64p1 - 1) spread32 = aw.span64p1 - 1;
+      g->strip_w = 32;
+      g->nstrips = (int)((oWe + 31) / 32);
+      g->nseg = ((spread32 + 4 * g->nq) * (int)C + 3 + (int)C + 3) / 4 + 1;
+    }
     return g->nseg <= 128;
   }
   g->nq = quads_for(taps_w, epq);

@@ -959,6 +959,27 @@ def test_plane_groups_equal_single_planes(aa):
         _lib.set_plane_groups(1)
 
 
+def test_fp32_channels_last_strong_downscale_is_fused(aa):
+    """fp32 channels_last at test.py's 906 -> 120 thumbnail width (17 bilinear taps): strips of 32 elements keep the staged segment
+    within the kernel's 128 pieces, so the shape runs fused (round 3; it was on the two-launch path); bit-identical to that path and to
+    the oracle."""
+    from interpolate_antialiasing_amd import _lib
+
+    torch.manual_seed(5)
+    for c in (3, 4):
+        x = (torch.rand(2, c, 438, 906, device="cuda") * 255).contiguous(memory_format=torch.channels_last)
+        y = aa.linear_forward(x, [96, 120])
+        assert _lib.last_variant() == "fused_f32_nhwc", (c, _lib.last_variant())
+        try:
+            _lib.set_fused(0)
+            y0 = aa.linear_forward(x, [96, 120])
+        finally:
+            _lib.set_fused(1)
+        assert torch.equal(y, y0), c
+        exp = oracle.forward("linear", x[:1].contiguous().cpu().numpy(), (96, 120))
+        assert np.array_equal(y[:1].contiguous().cpu().numpy(), exp), c
+
+
 def test_sixteen_bit_tensor_ending_on_its_allocation(aa):
     """Rows of 16-bit elements with an odd W: the dword that holds the tensor's final element straddles the end of the tensor.  The
     fused kernel must neither drop that element nor read the two bytes beyond it (round 3: the second form faulted once in 90 000
