@@ -3,5 +3,5 @@
 #include "aa_fused_u8_v3_impl.h"
 
 int aa_v3_launch_c3g(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
-  return dispatch_tw_planes(tw, maxc, p, q, lds);
+  return dispatch_tw_planes<3>(tw, maxc, p, q, lds);
 }

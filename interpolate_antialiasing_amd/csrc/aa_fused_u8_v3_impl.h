@@ -169,14 +169,15 @@ __device__ inline void wait_vmcnt(int n) {  // rounding n DOWN only waits longer
 //     phases, so the DMA reads from each segment's exact first byte (LDS-DMA serves any source alignment): every staged image then
 //     starts at LDS phase 0 and the window addresses are per-slot constants.  Price of unaligned dwords: the range check refuses a
 //     dword that straddles the end of the tensor, so the last 3 bytes of the tensor's very last row are fetched on their own
-//     (pl_patch_last; nothing is ever read past the tensor).  One single-channel window per plane, the same weights for all of them;
+//     (pl_patch_last; nothing is ever read past the tensor).  One single-channel window per plane, the same weights for all of them (either
+//     arithmetic: Pillow's integers, or FLT = the harness's floats with uint8 or float32 planes out);
 //     vertical pass and accumulators as for C interleaved channels; one 64-byte row piece stored per plane.  Pillow arithmetic,
 //     shrinking heights.
 template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0, int PL = 0>
 __global__ void __launch_bounds__(512) AA_V3_OCC
 fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const char *__restrict__ tab_w,
                         const char *__restrict__ tab_h, const FusedU8V3Params p) {
-  static_assert(PL == 0 || (PL == C && !PERIODIC && !FLT && UPK == 0 && !TWO_DMA), "plane groups: Pillow arithmetic, shrinking heights, generic addressing");
+  static_assert(PL == 0 || (PL == C && !PERIODIC && UPK == 0 && !TWO_DMA), "plane groups: shrinking heights, fixed stage layout");
   constexpr int PLN = PL > 0 ? PL : 1;  // windows per lane and row
   constexpr int CB = PL > 0 ? 1 : C;    // bytes per pixel in a staged row
   constexpr int NV1 = (CB * TW + 3) / 4;  // dwords holding one window
@@ -477,7 +478,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     } else if constexpr (PL > 0) {
       // the lane's PL bytes in one register; per plane, the quad's four bytes are merged into its first lane in two steps (pairs, then
       // the pair of pairs): one DPP move shared by the planes + per plane one byte permute, one DPP move, one byte permute
-      const unsigned t = pack4_clip8(A[0][0], A[0][1], A[0][PL > 2 ? 2 : 1], A[0][PL - 1]);
+      const unsigned t = FLT ? (trunc8(A[0][0]) | (trunc8(A[0][1]) << 8) | (trunc8(A[0][PL > 2 ? 2 : 1]) << 16))
+                             : pack4_clip8(A[0][0], A[0][1], A[0][PL > 2 ? 2 : 1], A[0][PL - 1]);
       const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xF5 /*quad_perm:[1,1,3,3]*/, 0xF, 0xF, false);
 #pragma unroll
       for (int c = 0; c < PL; c++) {
@@ -555,7 +557,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       for (int j = 0; j < TW; j++) {
 #pragma unroll
         for (int c = 0; c < C; c++) {
-          const int bi = j * C + c;
+          const int bi = PL > 0 ? c * (4 * NV1) + j : j * C + c;  // (plane groups: channel c's own window)
           const float px = (float)((v[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
           if constexpr (AA_V3_FLT_FAST != 0) {
             accf[c] = j == 0 ? px * __int_as_float(wreg[j]) : __builtin_fmaf(px, __int_as_float(wreg[j]), accf[c]);
@@ -929,21 +931,38 @@ int dispatch_tw_wide(int tw, int maxc, const FusedU8V3Params &p, const AAProblem
 }
 
 // plane groups (template parameter PL): the three planes of a planar image in one wave; instantiated in aa_fused_u8_v3_c3g.hip
-template <int TW>
+// (templates over the plane count so that only the translation units that name them instantiate the kernels)
+template <int PLANES, int TW>
 int launch_planes(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  static_assert(PLANES == 3, "three planes");
   const bool nonneg = q.aw.filter != AA_FILTER_CUBIC && q.ah.filter != AA_FILTER_CUBIC;
   if (maxc <= 2) return nonneg ? launch_k<3, TW, 8, 2, false, true, false, false, 0, 3>(p, q, lds, 0) : launch_k<3, TW, 8, 2, false, false, false, false, 0, 3>(p, q, lds, 0);
   if (maxc <= 3) return nonneg ? launch_k<3, TW, 8, 3, false, true, false, false, 0, 3>(p, q, lds, 0) : launch_k<3, TW, 8, 3, false, false, false, false, 0, 3>(p, q, lds, 0);
   return nonneg ? launch_k<3, TW, 8, 4, false, true, false, false, 0, 3>(p, q, lds, 0) : launch_k<3, TW, 8, 4, false, false, false, false, 0, 3>(p, q, lds, 0);
 }
-inline int dispatch_tw_planes(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+// ... in float arithmetic (harness semantics, float32 planes out): aa_fused_u8_v3_c3gf.hip, and c3gff.hip for the tolerance mode
+template <int PLANES, int TW>
+int launch_planes_flt(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  static_assert(PLANES == 3, "three planes");
+  if (maxc <= 2) return launch_k<3, TW, 8, 2, false, false, false, true, 0, 3>(p, q, lds, 0);
+  if (maxc <= 3) return launch_k<3, TW, 8, 3, false, false, false, true, 0, 3>(p, q, lds, 0);
+  return launch_k<3, TW, 8, 4, false, false, false, true, 0, 3>(p, q, lds, 0);
+}
+template <int PLANES>
+int dispatch_tw_planes_flt(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
   if (maxc > 4) return 0;
-  if (tw <= 4) return launch_planes<4>(maxc, p, q, lds);
-  if (tw <= 6) return launch_planes<6>(maxc, p, q, lds);
-  if (tw <= 8) return launch_planes<8>(maxc, p, q, lds);
-  if (tw <= 12) return launch_planes<12>(maxc, p, q, lds);
-  if (tw <= 16) return launch_planes<16>(maxc, p, q, lds);
-  return 0;
+  if (tw <= 6) return launch_planes_flt<PLANES, 6>(maxc, p, q, lds);
+  if (tw <= 8) return launch_planes_flt<PLANES, 8>(maxc, p, q, lds);
+  return 0;  // (12 taps in float arithmetic: 133-141 VGPRs, three waves per SIMD — the single-plane form keeps them)
+}
+template <int PLANES>
+int dispatch_tw_planes(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  if (maxc > 4) return 0;
+  if (tw <= 4) return launch_planes<PLANES, 4>(maxc, p, q, lds);
+  if (tw <= 6) return launch_planes<PLANES, 6>(maxc, p, q, lds);
+  if (tw <= 8) return launch_planes<PLANES, 8>(maxc, p, q, lds);
+  if (tw <= 12) return launch_planes<PLANES, 12>(maxc, p, q, lds);
+  return 0;  // (16 taps: 147 VGPRs, three waves per SIMD — the single-plane form is faster)
 }
 
 // growing heights (gather-form vertical pass): generic window addressing, one DMA per row, no scatter accumulators.  Ring of 2
@@ -995,6 +1014,8 @@ int aa_v3_launch_c3w(int tw, int maxc, const FusedU8V3Params &p, const AAProblem
 int aa_v3_launch_c4w(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 // plane groups: planar images of three channels (aa_fused_u8_v3_c3g.hip)
 int aa_v3_launch_c3g(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c3gf(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);   // float arithmetic
+int aa_v3_launch_c3gff(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);  // ... in the tolerance mode
 // growing heights (aa_fused_u8_v3_c{1,3,4}u.hip)
 int aa_v3_launch_up_c1(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_up_c3(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);

@@ -945,6 +945,28 @@ def test_plane_groups_equal_single_planes(aa):
             assert v1 == v2 == "fused_u8_planar_pil_v3", (shape, out, v1, v2)
             assert torch.equal(y1, y0), (shape, out, filt, "plane groups")
             assert torch.equal(y2, y0), (shape, out, filt, "single planes")
+        # float arithmetic (test.py's own path: CHW bytes, float(), op, byte()) and float32 planes out, exact and in the tolerance mode
+        for shape, out, filt in (((3, 3, 90, 438), (40, 196), "linear"), ((2, 3, 131, 307), (37, 101), "linear"), ((2, 3, 70, 301), (31, 150), "cubic")):
+            x = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda")
+            fn = _fn(aa, filt)
+            for kw, want in (({"uint8_mode": "harness"}, "fused_u8_planar_harness_v3"),
+                             ({"out_dtype": torch.float32, "mean": [1.0, 2.0, 3.0], "std": [2.0, 3.0, 4.0]}, "fused_u8_planar_to_f32_v3")):
+                _lib.set_plane_groups(1)
+                y1 = fn(x, list(out), **kw)
+                v1 = _lib.last_variant()
+                yf = fn(x, list(out), precision="fast", **kw)
+                vf = _lib.last_variant()
+                _lib.set_plane_groups(0)
+                y2 = fn(x, list(out), **kw)
+                _lib.set_fused(0)
+                y0 = fn(x, list(out), **kw)
+                _lib.set_fused(1)
+                assert v1 == want and vf == want + "_fast", (shape, out, v1, vf)
+                assert torch.equal(y1, y0) and torch.equal(y2, y0), (shape, out, filt, want)
+                if y1.dtype == torch.uint8:
+                    assert (yf.int() - y0.int()).abs().max().item() <= 1
+                else:
+                    torch.testing.assert_close(yf, y0, rtol=1e-4, atol=1e-3)
         _lib.set_plane_groups(1)
         x = torch.randint(0, 256, (2, 3, 45, 77), dtype=torch.uint8, device="cuda")
         y = aa.linear_forward(x, [17, 30])
