@@ -490,7 +490,9 @@ int launch_interleaved(int nq, int maxc, const FusedF32Params &p, const AAProble
     case 2: return launch_q<2, AA_F32, CS>(maxc, p, q);
     case 3: return launch_q<3, AA_F32, CS>(maxc, p, q);
     case 4: return launch_q<4, AA_F32, CS>(maxc, p, q);
-    default: return launch_q<5, AA_F32, CS>(maxc, p, q);
+    case 5: return launch_q<5, AA_F32, CS>(maxc, p, q);
+    case 7: return launch_q<7, AA_F32, CS>(maxc, p, q);
+    default: return launch_q<9, AA_F32, CS>(maxc, p, q);  // (36 taps: test.py's bicubic 906 -> 120 thumbnails, 33 taps)
   }
 }
 
@@ -524,7 +526,7 @@ bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw
   if (aw.span64p1 <= 0) return false;
   if (g->cs != 1) {  // interleaved channels (fp32, 3 or 4 of them): a lane per output element, taps read one by one
     if (dtype != AA_F32 || (C != 3 && C != 4) || aw.span4p1 <= 0) return false;
-    g->nq = taps_w <= 8 ? 2 : (taps_w <= 12 ? 3 : (taps_w <= 16 ? 4 : (taps_w <= 20 ? 5 : 0)));
+    g->nq = taps_w <= 8 ? 2 : (taps_w <= 12 ? 3 : (taps_w <= 16 ? 4 : (taps_w <= 20 ? 5 : (taps_w <= 28 ? 7 : (taps_w <= 36 ? 9 : 0)))));
     if (g->nq == 0 || W < 4 * g->nq) return false;
     const int64_t oWe = aw.out_size * C;
     g->strip_w = 64;

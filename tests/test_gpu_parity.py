@@ -1000,6 +1000,16 @@ def test_fp32_channels_last_strong_downscale_is_fused(aa):
         assert torch.equal(y, y0), c
         exp = oracle.forward("linear", x[:1].contiguous().cpu().numpy(), (96, 120))
         assert np.array_equal(y[:1].contiguous().cpu().numpy(), exp), c
+        # bicubic: 33 taps (9 quads of window positions, vector-register lane masks), and 25 taps (7 quads)
+        for size in ([96, 120], [110, 160]):
+            y = aa.cubic_forward(x, size)
+            assert _lib.last_variant() == "fused_f32_nhwc", (c, size, _lib.last_variant())
+            try:
+                _lib.set_fused(0)
+                y0 = aa.cubic_forward(x, size)
+            finally:
+                _lib.set_fused(1)
+            assert torch.equal(y, y0), (c, size)
 
 
 def test_sixteen_bit_tensor_ending_on_its_allocation(aa):
