@@ -497,8 +497,8 @@ int launch_interleaved(int nq, int maxc, const FusedF32Params &p, const AAProble
 }
 
 // window quads for a table whose widest window has `taps` taps: EPQ * NQ - (EPQ - 1) >= taps.  fp32: 2,3,4,5,7 quads of 4
-// floats (5 .. 25 taps); 16-bit floats: 2 or 3 quads of 8 (9 / 17 taps: more positions would not leave scalar registers
-// for their lane masks)
+// floats (5 .. 25 taps); 16-bit floats: 2, 3 or 5 quads of 8 (9 / 17 / 33 taps; beyond 28 window positions the lane masks live in
+// vector registers, see ANDM)
 int quads_for(int taps, int epq) {
   if (epq == 2) {  // doubles: 2 per aligned read, taps <= 2 * NQ - 1
     const int opts[] = {2, 4, 6, 8, 11};
@@ -514,6 +514,7 @@ int quads_for(int taps, int epq) {
   }
   if (taps <= 9) return 2;
   if (taps <= 17) return 3;
+  if (taps <= 33) return 5;  // (40 window positions: vector-register lane masks, as for 9 quads of fp32)
   return 0;
 }
 
@@ -645,9 +646,9 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
     }
 #endif
   } else if (q.dtype == AA_F16) {
-    rc = g.nq == 2 ? launch_q<2, AA_F16>(mc, p, q) : launch_q<3, AA_F16>(mc, p, q);
+    rc = g.nq == 2 ? launch_q<2, AA_F16>(mc, p, q) : (g.nq == 3 ? launch_q<3, AA_F16>(mc, p, q) : launch_q<5, AA_F16>(mc, p, q));
   } else {
-    rc = g.nq == 2 ? launch_q<2, AA_BF16>(mc, p, q) : launch_q<3, AA_BF16>(mc, p, q);
+    rc = g.nq == 2 ? launch_q<2, AA_BF16>(mc, p, q) : (g.nq == 3 ? launch_q<3, AA_BF16>(mc, p, q) : launch_q<5, AA_BF16>(mc, p, q));
   }
 #if AA_F32_FAST
   if (rc == 1) *variant = q.dtype == AA_F32 ? "fused_f32_nchw_fast" : (q.dtype == AA_F16 ? "fused_f16_nchw_fast" : "fused_bf16_nchw_fast");

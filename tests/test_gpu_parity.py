@@ -1012,6 +1012,33 @@ def test_fp32_channels_last_strong_downscale_is_fused(aa):
             assert torch.equal(y, y0), (c, size)
 
 
+def test_sixteen_bit_wide_windows_are_fused(aa):
+    """fp16 / bf16 planes with 18 .. 33 taps (test.py's bicubic 906 -> 120 thumbnails; config 2's bicubic 1024 -> 224 in halves): five quads
+    of eight window positions, lane masks in vector registers.  Bit-identical to the two-launch path and to half(oracle_fp32(float(x)));
+    the tolerance mode within its bar."""
+    from interpolate_antialiasing_amd import _lib
+
+    torch.manual_seed(6)
+    for dt, name in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        for shape, size in (((2, 3, 438, 906), [96, 120]), ((2, 3, 1024, 1024), [224, 224]), ((1, 2, 300, 701), [70, 100])):
+            x = (torch.rand(*shape, device="cuda") * 255).to(dt)
+            y = aa.cubic_forward(x, size)
+            assert _lib.last_variant() == f"fused_{name}_nchw", (name, shape, _lib.last_variant())
+            yf = aa.cubic_forward(x, size, precision="fast")
+            assert _lib.last_variant() == f"fused_{name}_nchw_fast", _lib.last_variant()
+            try:
+                _lib.set_fused(0)
+                y0 = aa.cubic_forward(x, size)
+            finally:
+                _lib.set_fused(1)
+            assert torch.equal(y.view(torch.int16), y0.view(torch.int16)), (name, shape)
+            torch.testing.assert_close(yf.float(), y0.float(), rtol=2e-2, atol=2.0)
+        x = (torch.rand(1, 1, 120, 400, device="cuda") * 255).to(dt)
+        y = aa.cubic_forward(x, [30, 55])
+        exp = torch.from_numpy(oracle.forward("cubic", x.float().cpu().numpy(), (30, 55))).to(dt)
+        assert torch.equal(y.cpu().view(torch.int16), exp.view(torch.int16)), name
+
+
 def test_sixteen_bit_tensor_ending_on_its_allocation(aa):
     """Rows of 16-bit elements with an odd W: the dword that holds the tensor's final element straddles the end of the tensor.  The
     fused kernel must neither drop that element nor read the two bytes beyond it (round 3: the second form faulted once in 90 000
