@@ -28,14 +28,14 @@ static bool v3_shape_ok(int dtype, int layout, int64_t N, int64_t Cin, int64_t H
     if (planar && oW > 256) return false;
   } else {  // the in-register scatter pass needs the H table's scatter section and at most 4 open output rows
     if (ah.scatter_off <= 0 || ah.scatter_max <= 0 || ah.scatter_max > 6) return false;
-    if (ah.scatter_max > 4 && (flt || (aw.max_taps > 0 ? aw.max_taps : aw.ksize) <= 16)) return false;  // (6 open rows: the wide-window instantiations only)
+    if (ah.scatter_max > 4 && (aw.max_taps > 0 ? aw.max_taps : aw.ksize) <= 16) return false;  // (6 open rows: the wide-window instantiations only)
   }
   const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
   int tw = round_tw(taps_w);
   if (flt && tw != 0 && tw < 6) tw = 6;  // the float variant is instantiated for windows of 6, 8, 12 and 16 taps
   // windows of 17 .. 34 taps: Pillow arithmetic, shrinking heights.  (With growing heights — test.py's (120, 1200) — the gather form with
   // such windows was built and measured SLOWER than the two-launch path: bicubic channels_last 0.226 vs 0.205 ms per 128 images.)
-  if (tw > 16 && (flt || up)) return false;
+  if (tw > 16 && up) return false;
   if (tw == 0 || W < tw) return false;
   if ((uint64_t)H * W * C > 0x7FFFFFF0ull || (uint64_t)oH * oW * C > 0xFFFFFFF0ull) return false;
   int span_px = aa_strip_span_px(aw, tw);
@@ -157,10 +157,13 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
          : C == 4 ? aa_v3_launch_up_c4(tw, taps_h, nonneg, flt, p, q, lds)
                   : aa_v3_launch_up_c1(tw, taps_h, nonneg, flt, p, q, lds);
   } else {
-    if (flt && q.fast) {  // the tolerance mode of the float-arithmetic kernels (down-scaling heights only; growing heights run exact)
+    if (flt && q.fast && tw <= 16) {  // the tolerance mode of the float-arithmetic kernels (down-scaling heights only; growing heights run exact)
       p.fast = 1;
       rc = C == 3 ? aa_v3_launch_c3ff(tw, q.ah.scatter_max, p, q, lds) : C == 4 ? aa_v3_launch_c4ff(tw, q.ah.scatter_max, p, q, lds)
                                                                                  : aa_v3_launch_c1ff(tw, q.ah.scatter_max, p, q, lds);
+    } else if (tw > 16 && flt) {  // (wide windows in float arithmetic run exact in either precision mode)
+      rc = C == 3 ? aa_v3_launch_c3wf(tw, q.ah.scatter_max, p, q, lds) : C == 4 ? aa_v3_launch_c4wf(tw, q.ah.scatter_max, p, q, lds)
+                                                                                : aa_v3_launch_c1wf(tw, q.ah.scatter_max, p, q, lds);
     } else if (tw > 16) {
       rc = C == 3 ? aa_v3_launch_c3w(tw, q.ah.scatter_max, p, q, lds) : C == 4 ? aa_v3_launch_c4w(tw, q.ah.scatter_max, p, q, lds)
                                                                                : aa_v3_launch_c1w(tw, q.ah.scatter_max, p, q, lds);
@@ -169,7 +172,7 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
          : C == 4 ? aa_v3_launch_c4(tw, q.ah.scatter_max, flt, p, q, lds)
                   : aa_v3_launch_c1(tw, q.ah.scatter_max, flt, p, q, lds);
   }
-  const bool fastv = flt && q.fast && !up;
+  const bool fastv = flt && q.fast && !up && tw <= 16;
   if (rc == 1 && q.out_f32) *variant = planar ? (fastv ? "fused_u8_planar_to_f32_v3_fast" : "fused_u8_planar_to_f32_v3")
                                               : (p.outm == 1 ? (fastv ? "fused_u8_nhwc_to_f32_nchw_v3_fast" : "fused_u8_nhwc_to_f32_nchw_v3")
                                                              : (fastv ? "fused_u8_nhwc_to_f32_nhwc_v3_fast" : "fused_u8_nhwc_to_f32_nhwc_v3"));

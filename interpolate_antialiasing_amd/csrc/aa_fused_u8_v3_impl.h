@@ -930,6 +930,22 @@ int dispatch_tw_wide(int tw, int maxc, const FusedU8V3Params &p, const AAProblem
   return 0;
 }
 
+// ... and in float arithmetic (the harness's semantics, float32 out): aa_fused_u8_v3_c{1,3,4}wf.hip
+template <int C, int TW>
+int launch_wide_flt(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  const bool two = p.nseg > 64;
+  if (maxc <= 2) return two ? launch_k<C, TW, 8, 2, true, false, false, true>(p, q, lds, 0) : launch_k<C, TW, 8, 2, false, false, false, true>(p, q, lds, 0);
+  if (maxc <= 3) return two ? launch_k<C, TW, 8, 3, true, false, false, true>(p, q, lds, 0) : launch_k<C, TW, 8, 3, false, false, false, true>(p, q, lds, 0);
+  if (maxc <= 4) return two ? launch_k<C, TW, 8, 4, true, false, false, true>(p, q, lds, 0) : launch_k<C, TW, 8, 4, false, false, false, true>(p, q, lds, 0);
+  return two ? launch_k<C, TW, 8, 6, true, false, false, true>(p, q, lds, 0) : launch_k<C, TW, 8, 6, false, false, false, true>(p, q, lds, 0);
+}
+template <int C>
+int dispatch_tw_wide_flt(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  if (tw <= 24) return launch_wide_flt<C, 24>(maxc, p, q, lds);
+  if (tw <= 34) return launch_wide_flt<C, 34>(maxc, p, q, lds);
+  return 0;
+}
+
 // plane groups (template parameter PL): the three planes of a planar image in one wave; instantiated in aa_fused_u8_v3_c3g.hip
 // (templates over the plane count so that only the translation units that name them instantiate the kernels)
 template <int PLANES, int TW>
@@ -1016,6 +1032,10 @@ int aa_v3_launch_c4w(int tw, int maxc, const FusedU8V3Params &p, const AAProblem
 int aa_v3_launch_c3g(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c3gf(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);   // float arithmetic
 int aa_v3_launch_c3gff(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);  // ... in the tolerance mode
+// wide windows in float arithmetic (aa_fused_u8_v3_c{1,3,4}wf.hip)
+int aa_v3_launch_c1wf(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c3wf(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c4wf(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 // growing heights (aa_fused_u8_v3_c{1,3,4}u.hip)
 int aa_v3_launch_up_c1(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_up_c3(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);

@@ -1413,6 +1413,35 @@ def test_wide_windows_take_the_fused_uint8_kernel(aa, golden_kat):
                 assert torch.equal(y1, y0), (filt, size, planar)
                 exp = oracle.pil_resize_u8(filt, x.cpu().numpy(), size)
                 assert np.array_equal(y1.cpu().numpy(), exp), (filt, size, planar)
+    # the same windows in the harness's float arithmetic (uint8 out) and as float32 planes out (round 3): bit-identical to the two-launch
+    # path and to the oracle's harness restatement; precision="fast" runs the exact wide kernel (no tolerance instantiation that wide)
+    for filt in ("linear", "cubic"):
+        for size in ((96, 120), (60, 200)):
+            for planar in (False, True):
+                x = x_hwc.permute(0, 3, 1, 2)
+                x = x.contiguous() if planar else x
+                for kw, want in (({"uint8_mode": "harness"}, "fused_u8_planar_harness_v3" if planar else "fused_u8_nhwc_harness_v3"),
+                                 ({"out_dtype": torch.float32, "out_format": "nchw"}, "fused_u8_planar_to_f32_v3" if planar else "fused_u8_nhwc_to_f32_nchw_v3")):
+                    try:
+                        _lib.set_fused(1)
+                        y1 = _fn(aa, filt)(x, list(size), **kw)
+                        v1 = _lib.last_variant()
+                        yf = _fn(aa, filt)(x, list(size), precision="fast", **kw)
+                        vf = _lib.last_variant()
+                        _lib.set_fused(0)
+                        y0 = _fn(aa, filt)(x, list(size), **kw)
+                    finally:
+                        _lib.set_fused(1)
+                    assert v1 == want and vf in (want, want + "_fast"), (v1, vf, want, filt, size)  # (_fast: windows of up to 16 taps)
+                    assert torch.equal(y1, y0), (filt, size, planar, want)
+                    if vf == want:
+                        assert torch.equal(yf, y0), (filt, size, planar, want)
+                    elif yf.dtype == torch.uint8:
+                        assert (yf.int() - y0.int()).abs().max().item() <= 1
+                    else:
+                        torch.testing.assert_close(yf, y0, rtol=1e-4, atol=1e-3)
+                    if "uint8_mode" in kw:
+                        assert np.array_equal(y1.cpu().numpy(), oracle.harness_u8(filt, x.cpu().numpy(), size)), (filt, size, planar)
     # fp32 planes: 33-tap windows (9 aligned reads per row, lane masks in vector registers) on strips of 32 columns
     xf = x_hwc.permute(0, 3, 1, 2).float().contiguous()
     for filt, size in (("cubic", (96, 120)), ("cubic", (200, 130)), ("linear", (60, 110))):
