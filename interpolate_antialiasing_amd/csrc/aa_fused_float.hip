@@ -120,6 +120,17 @@ template <> __device__ inline float elem_to_f32<AA_F16>(unsigned bits) {
   return (float)c.h;
 }
 template <> __device__ inline float elem_to_f32<AA_BF16>(unsigned bits) { return __uint_as_float(bits << 16); }
+// fp16 windows: v_fma_mix_f32 takes the half straight from either half of the packed register (one instruction instead of a conversion
+// and a multiply).  fma(float(h), w, c) with c = -0.0f IS the separately rounded product the reference computes — the conversion is
+// exact and adding -0 changes neither a value nor the sign of a zero product — and with c = the accumulator it is the tolerance mode's
+// fused multiply-add.  (Halves that are denormal follow the same FP16 denormal mode as v_cvt_f32_f16.)
+template <int HI>
+__device__ inline float fma_mix_f16(unsigned packed, float w, float c) {
+  float d;
+  if constexpr (HI != 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(w), "v"(c));
+  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(w), "v"(c));
+  return d;
+}
 template <int DT> __device__ inline unsigned f32_to_elem(float a);
 template <> __device__ inline unsigned f32_to_elem<AA_F32>(float a) { return __float_as_uint(a); }
 template <> __device__ inline unsigned f32_to_elem<AA_F16>(float a) {
@@ -297,6 +308,8 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
     for (int k2 = 0; k2 + 1 < MAXC; k2++) A[k2] = A[k2 + 1];
     A[MAXC - 1] = (real)-0.0;
   };
+  float neg_zero = -0.0f;
+  asm volatile("" : "+v"(neg_zero));  // (a register operand for fma_mix_f16)
   // one input row: window from LDS, reference-order accumulation over the lane's own taps, scatter into the open outputs
   auto row_step = [&](int slot, const Scatter &sc) {
     const __attribute__((address_space(3))) u32x4 *src =
@@ -314,6 +327,21 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
     real acc = (real)-0.0;
 #pragma unroll
     for (int q = 0; q < TWP; q++) {
+      if constexpr (DT == AA_F16) {  // (see fma_mix_f16)
+        const unsigned pk = d[q >> 3][(q >> 1) & 3];
+        if constexpr (AA_F32_FAST != 0) {
+          acc = (q & 1) ? fma_mix_f16<1>(pk, wreg[q], acc) : fma_mix_f16<0>(pk, wreg[q], acc);
+        } else {
+          const float prod = (q & 1) ? fma_mix_f16<1>(pk, wreg[q], neg_zero) : fma_mix_f16<0>(pk, wreg[q], neg_zero);
+          if constexpr (ANDM) {
+            acc = sub_masked(acc, prod, mk[q]);
+          } else {
+            const float sum = acc + prod;
+            acc = select_by_mask(acc, sum, inwin[q]);
+          }
+        }
+        continue;
+      }
       real dq;  // window position q as a real
       if constexpr (CS != 1) dq = dt[q];
       else if constexpr (DT == AA_F64) dq = __longlong_as_double(((unsigned long long)d[q >> 1][2 * (q & 1) + 1] << 32) | d[q >> 1][2 * (q & 1)]);

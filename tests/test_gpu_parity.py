@@ -1039,6 +1039,36 @@ def test_sixteen_bit_wide_windows_are_fused(aa):
         assert torch.equal(y.cpu().view(torch.int16), exp.view(torch.int16)), name
 
 
+def test_fp16_products_are_the_references(aa):
+    """The fp16 kernel multiplies with v_fma_mix_f32 (half operand taken straight from the packed register, addend -0.0): the product must
+    be the separately rounded float(h) * w of the reference in every corner — denormal halves, signed zeros (a zero product keeps its sign,
+    so an all-zero window gives the reference's zero), large magnitudes, negative bicubic weights — bit-identical to the two-launch path,
+    which converts with v_cvt_f32_f16 and multiplies."""
+    from interpolate_antialiasing_amd import _lib
+
+    torch.manual_seed(9)
+    x = (torch.rand(2, 3, 200, 333, device="cuda") * 255).half()
+    x[0, 0, :50] = 0.0
+    x[0, 1, :50] = -0.0
+    x[0, 2, 10:60, 20:200] = torch.tensor(6.0e-8, dtype=torch.float16, device="cuda")      # the smallest denormal half
+    x[1, 0, 100:150] = (torch.rand(50, 333, device="cuda") * 6.0e-5).half()               # denormals and tiny normals
+    x[1, 1, 30:90, 50:300] = -(torch.rand(60, 250, device="cuda") * 6.0e4).half()         # large negatives
+    x[1, 2, ::3] = 65504.0
+    for fn, size in ((aa.linear_forward, [90, 150]), (aa.cubic_forward, [90, 150]), (aa.cubic_forward, [40, 44]), (aa.linear_forward, [200, 120])):
+        y = fn(x, size)
+        assert _lib.last_variant() == "fused_f16_nchw", _lib.last_variant()
+        try:
+            _lib.set_fused(0)
+            y0 = fn(x, size)
+        finally:
+            _lib.set_fused(1)
+        assert torch.equal(y.view(torch.int16), y0.view(torch.int16)), size   # bit patterns: -0.0 and +0.0 are told apart
+        yf = fn(x, size, precision="fast")
+        assert _lib.last_variant() == "fused_f16_nchw_fast"
+        ok = torch.isfinite(y0.float())
+        torch.testing.assert_close(yf.float()[ok], y0.float()[ok], rtol=2e-3, atol=1e-3)
+
+
 def test_sixteen_bit_tensor_ending_on_its_allocation(aa):
     """Rows of 16-bit elements with an odd W: the dword that holds the tensor's final element straddles the end of the tensor.  The
     fused kernel must neither drop that element nor read the two bytes beyond it (round 3: the second form faulted once in 90 000
