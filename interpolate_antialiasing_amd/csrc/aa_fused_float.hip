@@ -47,6 +47,9 @@ namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int BYTES> struct ReadUnit { typedef u32x4 type; };  // one aligned LDS read of a window
+template <> struct ReadUnit<8> { typedef u32x2 type; };
 
 __device__ inline float fma_real(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ inline double fma_real(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -157,7 +160,12 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
                       const char *__restrict__ tab_h, const FusedF32Params p) {
   typedef typename RealOf<DT>::type real;  // arithmetic type: double for AA_F64 planes (AA_TABLE_F64 tables), else float
   constexpr int ES = DT == AA_F64 ? 8 : (DT == AA_F32 ? 4 : 2);  // element bytes
-  constexpr int EPQ = 16 / ES;              // elements per aligned 16-byte read
+  // bytes per aligned LDS read of a window: 16, but 8 for 16-bit elements (round 3) — a window starts anywhere on the read grid, so it
+  // spans its taps + up to EPQ - 1 wasted positions, each costing its conversion, multiply, add and select: 4 elements per read
+  // instead of 8 cut the positions of a 7-tap window from 16 to 12, of an 11-tap one from 24 to 16, of a 21-tap one from 40 to 28
+  constexpr int RB = ES == 2 ? 8 : 16;
+  typedef typename ReadUnit<RB>::type unit_t;
+  constexpr int EPQ = RB / ES;              // elements per aligned read
   constexpr int TWP = EPQ * NQ;
   constexpr int TW = CS == 1 ? TWP - (EPQ - 1) : TWP;  // taps a lane can hold
   // more than 28 window positions: their lane masks no longer fit the scalar registers (two per position), so the AND form is used —
@@ -228,7 +236,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   // lane 0 is always active and its PIXEL has the smallest window start (interleaved channels: take its channel 0, a
   // neighbouring pixel with the same start and a lower channel sits before lane 0's own element)
   const int seg0 = __builtin_amdgcn_readfirstlane(CS == 1 ? astart : astart - (oe - ox * CS)) & ~(EPQ - 1);
-  const unsigned lane_lds = (unsigned)(wv * G * p.seg_bytes + (astart - seg0) * ES);  // multiple of 16
+  const unsigned lane_lds = (unsigned)(wv * G * p.seg_bytes + (astart - seg0) * ES);  // multiple of RB
 
   const unsigned long long plane_off = (unsigned long long)plane * p.plane_in_bytes;
   unsigned long long remaining = p.total_in_bytes - plane_off;
@@ -312,9 +320,9 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   asm volatile("" : "+v"(neg_zero));  // (a register operand for fma_mix_f16)
   // one input row: window from LDS, reference-order accumulation over the lane's own taps, scatter into the open outputs
   auto row_step = [&](int slot, const Scatter &sc) {
-    const __attribute__((address_space(3))) u32x4 *src =
-        (const __attribute__((address_space(3))) u32x4 *)(uintptr_t)(lane_lds + (unsigned)(slot * p.seg_bytes));
-    u32x4 d[NQ];
+    const __attribute__((address_space(3))) unit_t *src =
+        (const __attribute__((address_space(3))) unit_t *)(uintptr_t)(lane_lds + (unsigned)(slot * p.seg_bytes));
+    unit_t d[NQ];
     float dt[CS == 1 ? 1 : TWP];  // (interleaved channels: the taps, CS floats apart)
     if constexpr (CS == 1) {
 #pragma unroll
@@ -328,7 +336,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
 #pragma unroll
     for (int q = 0; q < TWP; q++) {
       if constexpr (DT == AA_F16) {  // (see fma_mix_f16)
-        const unsigned pk = d[q >> 3][(q >> 1) & 3];
+        const unsigned pk = d[q >> 2][(q >> 1) & 1];
         if constexpr (AA_F32_FAST != 0) {
           acc = (q & 1) ? fma_mix_f16<1>(pk, wreg[q], acc) : fma_mix_f16<0>(pk, wreg[q], acc);
         } else {
@@ -346,7 +354,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
       if constexpr (CS != 1) dq = dt[q];
       else if constexpr (DT == AA_F64) dq = __longlong_as_double(((unsigned long long)d[q >> 1][2 * (q & 1) + 1] << 32) | d[q >> 1][2 * (q & 1)]);
       else if constexpr (DT == AA_F32) dq = __uint_as_float(d[q >> 2][q & 3]);
-      else dq = elem_to_f32<DT>(d[q >> 3][(q >> 1) & 3] >> (16 * (q & 1)));
+      else dq = elem_to_f32<DT>(d[q >> 2][(q >> 1) & 1] >> (16 * (q & 1)));
       if constexpr (AA_F32_FAST != 0) {  // tolerance mode: the weight is zero outside the lane's own taps
         acc = fma_real(dq, wreg[q], acc);
         continue;
@@ -388,8 +396,8 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   // 16-bit elements, odd W: the staged image of the tensor's very last row lacks its final element (see fix_row); lane 0 reads
   // that element with an ordinary 2-byte load and puts it (and a zero for the position beyond the row) into the slot
   auto patch_last = [&](int slot) {
-    const int pos = p.Wp - 1 - seg0;  // position inside the strip's segment (even: seg0 is a multiple of 8, W is odd)
-    if (pos < 0 || pos >= p.nseg * EPQ) return;
+    const int pos = p.Wp - 1 - seg0;  // position inside the strip's segment (even: seg0 is a multiple of 4, W is odd)
+    if (pos < 0 || pos >= p.nseg * (16 / ES)) return;
     if (lane == 0) {
       const unsigned short v = *(const unsigned short *)((const uint8_t *)in + plane_off + (unsigned long long)(p.H - 1) * row_bytes +
                                                          (unsigned long long)(p.Wp - 1) * 2u);
@@ -525,8 +533,8 @@ int launch_interleaved(int nq, int maxc, const FusedF32Params &p, const AAProble
 }
 
 // window quads for a table whose widest window has `taps` taps: EPQ * NQ - (EPQ - 1) >= taps.  fp32: 2,3,4,5,7 quads of 4
-// floats (5 .. 25 taps); 16-bit floats: 2, 3 or 5 quads of 8 (9 / 17 / 33 taps; beyond 28 window positions the lane masks live in
-// vector registers, see ANDM)
+// floats (5 .. 25 taps) and 9 (33 taps; beyond 28 window positions the lane masks live in vector registers, see ANDM); 16-bit floats read
+// 8 bytes = 4 elements at a time and use the same table
 int quads_for(int taps, int epq) {
   if (epq == 2) {  // doubles: 2 per aligned read, taps <= 2 * NQ - 1
     const int opts[] = {2, 4, 6, 8, 11};
@@ -540,16 +548,15 @@ int quads_for(int taps, int epq) {
       if (taps <= 4 * o - 3) return o;
     return 0;
   }
-  if (taps <= 9) return 2;
-  if (taps <= 17) return 3;
-  if (taps <= 33) return 5;  // (40 window positions: vector-register lane masks, as for 9 quads of fp32)
   return 0;
 }
 
 struct F32Geometry { int nq, nstrips, strip_w, nseg, cs; };
 
 bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw, F32Geometry *g) {
-  const int es = dtype == AA_F64 ? 8 : (dtype == AA_F32 ? 4 : 2), epq = 16 / es;
+  const int es = dtype == AA_F64 ? 8 : (dtype == AA_F32 ? 4 : 2);
+  const int epq = es == 2 ? 4 : 16 / es;  // elements per aligned window read (8-byte reads for 16-bit elements, see the kernel)
+  const int pe = 16 / es;                 // elements per staged 16-byte piece
   const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
   g->cs = (layout == AA_NHWC && C > 1) ? (int)C : 1;
   if (aw.span64p1 <= 0) return false;
@@ -584,13 +591,13 @@ bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw
   g->nstrips = (int)((oW + 63) / 64);
   // elements a strip's windows cover: the spread of 64 window starts (+EPQ-1: the first one rounded down to the 16-byte
   // grid) + one window; in 16-byte pieces
-  g->nseg = (aw.span64p1 + (epq - 1) + epq * g->nq + (epq - 1)) / epq;
+  g->nseg = (aw.span64p1 + (epq - 1) + epq * g->nq + (pe - 1)) / pe;
   if (g->nseg > 128 && aw.span4p1 > 0) {  // strong down-scaling: strips of 32 columns (half the lanes idle; such a shape is bound by its input stream)
     const int by4 = 11 * (aw.span4p1 - 1) + 1;
     const int span32 = by4 < aw.span64p1 ? by4 : aw.span64p1;
     g->strip_w = 32;
     g->nstrips = (int)((oW + 31) / 32);
-    g->nseg = (span32 + (epq - 1) + epq * g->nq + (epq - 1)) / epq;
+    g->nseg = (span32 + (epq - 1) + epq * g->nq + (pe - 1)) / pe;
   }
   return g->nseg <= 128;
 }
@@ -674,9 +681,23 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
     }
 #endif
   } else if (q.dtype == AA_F16) {
-    rc = g.nq == 2 ? launch_q<2, AA_F16>(mc, p, q) : (g.nq == 3 ? launch_q<3, AA_F16>(mc, p, q) : launch_q<5, AA_F16>(mc, p, q));
+    switch (g.nq) {
+      case 2: rc = launch_q<2, AA_F16>(mc, p, q); break;
+      case 3: rc = launch_q<3, AA_F16>(mc, p, q); break;
+      case 4: rc = launch_q<4, AA_F16>(mc, p, q); break;
+      case 5: rc = launch_q<5, AA_F16>(mc, p, q); break;
+      case 7: rc = launch_q<7, AA_F16>(mc, p, q); break;
+      default: rc = launch_q<9, AA_F16>(mc, p, q); break;
+    }
   } else {
-    rc = g.nq == 2 ? launch_q<2, AA_BF16>(mc, p, q) : (g.nq == 3 ? launch_q<3, AA_BF16>(mc, p, q) : launch_q<5, AA_BF16>(mc, p, q));
+    switch (g.nq) {
+      case 2: rc = launch_q<2, AA_BF16>(mc, p, q); break;
+      case 3: rc = launch_q<3, AA_BF16>(mc, p, q); break;
+      case 4: rc = launch_q<4, AA_BF16>(mc, p, q); break;
+      case 5: rc = launch_q<5, AA_BF16>(mc, p, q); break;
+      case 7: rc = launch_q<7, AA_BF16>(mc, p, q); break;
+      default: rc = launch_q<9, AA_BF16>(mc, p, q); break;
+    }
   }
 #if AA_F32_FAST
   if (rc == 1) *variant = q.dtype == AA_F32 ? "fused_f32_nchw_fast" : (q.dtype == AA_F16 ? "fused_f16_nchw_fast" : "fused_bf16_nchw_fast");
