@@ -46,6 +46,12 @@
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
+#ifndef AA_F32_RB
+#define AA_F32_RB 16  // bytes per aligned window read of fp32 PLANES.  8 (2 floats per read: 22 window positions instead of 28 for the 21-tap
+                      // bicubic of config 2) was built and measured SLOWER: config 2 0.188-0.198 -> 0.227 ms, tolerance mode 0.18-0.195 -> 0.21 —
+                      // 11 ds_read_b64 per row instead of 7 ds_read_b128 cost more than 6 fewer multiply-add-select groups save.  16-bit
+                      // elements are the other way round (their positions carry a conversion each): they read 8 bytes
+#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <int BYTES> struct ReadUnit { typedef u32x4 type; };  // one aligned LDS read of a window
@@ -163,7 +169,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   // bytes per aligned LDS read of a window: 16, but 8 for 16-bit elements (round 3) — a window starts anywhere on the read grid, so it
   // spans its taps + up to EPQ - 1 wasted positions, each costing its conversion, multiply, add and select: 4 elements per read
   // instead of 8 cut the positions of a 7-tap window from 16 to 12, of an 11-tap one from 24 to 16, of a 21-tap one from 40 to 28
-  constexpr int RB = ES == 2 ? 8 : 16;
+  constexpr int RB = ES == 2 ? 8 : ((ES == 4 && CS == 1) ? AA_F32_RB : 16);
   typedef typename ReadUnit<RB>::type unit_t;
   constexpr int EPQ = RB / ES;              // elements per aligned read
   constexpr int TWP = EPQ * NQ;
@@ -353,7 +359,7 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
       real dq;  // window position q as a real
       if constexpr (CS != 1) dq = dt[q];
       else if constexpr (DT == AA_F64) dq = __longlong_as_double(((unsigned long long)d[q >> 1][2 * (q & 1) + 1] << 32) | d[q >> 1][2 * (q & 1)]);
-      else if constexpr (DT == AA_F32) dq = __uint_as_float(d[q >> 2][q & 3]);
+      else if constexpr (DT == AA_F32) dq = __uint_as_float(d[q / EPQ][q % EPQ]);
       else dq = elem_to_f32<DT>(d[q >> 2][(q >> 1) & 1] >> (16 * (q & 1)));
       if constexpr (AA_F32_FAST != 0) {  // tolerance mode: the weight is zero outside the lane's own taps
         acc = fma_real(dq, wreg[q], acc);
@@ -536,6 +542,12 @@ int launch_interleaved(int nq, int maxc, const FusedF32Params &p, const AAProble
 // floats (5 .. 25 taps) and 9 (33 taps; beyond 28 window positions the lane masks live in vector registers, see ANDM); 16-bit floats read
 // 8 bytes = 4 elements at a time and use the same table
 int quads_for(int taps, int epq) {
+  if (epq == 1) {  // fp32 planes read 2 floats at a time: taps <= 2 * NQ - 1
+    const int opts[] = {3, 4, 5, 6, 8, 11, 14, 17};
+    for (int o : opts)
+      if (taps <= 2 * o - 1) return o;
+    return 0;
+  }
   if (epq == 2) {  // doubles: 2 per aligned read, taps <= 2 * NQ - 1
     const int opts[] = {2, 4, 6, 8, 11};
     for (int o : opts)
@@ -555,7 +567,7 @@ struct F32Geometry { int nq, nstrips, strip_w, nseg, cs; };
 
 bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw, F32Geometry *g) {
   const int es = dtype == AA_F64 ? 8 : (dtype == AA_F32 ? 4 : 2);
-  const int epq = es == 2 ? 4 : 16 / es;  // elements per aligned window read (8-byte reads for 16-bit elements, see the kernel)
+  const int epq = es == 2 ? 4 : (es == 4 ? AA_F32_RB / 4 : 2);  // elements per aligned window read of a plane (see RB in the kernel)
   const int pe = 16 / es;                 // elements per staged 16-byte piece
   const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
   g->cs = (layout == AA_NHWC && C > 1) ? (int)C : 1;
@@ -584,7 +596,7 @@ bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw
     }
     return g->nseg <= 128;
   }
-  g->nq = quads_for(taps_w, epq);
+  g->nq = quads_for(taps_w, es == 4 && epq == 2 ? 1 : epq);  // (1: the fp32 table of 8-byte reads)
   if (g->nq == 0 || W < epq * g->nq - (epq - 1)) return false;
   const int64_t oW = aw.out_size;
   g->strip_w = 64;  // whole 128-byte lines per stored fp32 row piece (the last strip may be shorter)
@@ -663,12 +675,23 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
 #endif
   if (q.dtype == AA_F32) {
     switch (g.nq) {
+#if AA_F32_RB == 8
+      case 3: rc = launch_q<3, AA_F32>(mc, p, q); break;
+      case 4: rc = launch_q<4, AA_F32>(mc, p, q); break;
+      case 5: rc = launch_q<5, AA_F32>(mc, p, q); break;
+      case 6: rc = launch_q<6, AA_F32>(mc, p, q); break;
+      case 8: rc = launch_q<8, AA_F32>(mc, p, q); break;
+      case 11: rc = launch_q<11, AA_F32>(mc, p, q); break;
+      case 14: rc = launch_q<14, AA_F32>(mc, p, q); break;
+      default: rc = launch_q<17, AA_F32>(mc, p, q); break;
+#else
       case 2: rc = launch_q<2, AA_F32>(mc, p, q); break;
       case 3: rc = launch_q<3, AA_F32>(mc, p, q); break;
       case 4: rc = launch_q<4, AA_F32>(mc, p, q); break;
       case 5: rc = launch_q<5, AA_F32>(mc, p, q); break;
       case 7: rc = launch_q<7, AA_F32>(mc, p, q); break;
       default: rc = launch_q<9, AA_F32>(mc, p, q); break;
+#endif
     }
 #if !AA_F32_FAST
   } else if (q.dtype == AA_F64) {
