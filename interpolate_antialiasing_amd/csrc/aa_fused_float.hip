@@ -446,15 +446,22 @@ fused_f32_nchw_kernel(const void *__restrict__ in, void *__restrict__ out, const
   }
 }
 
-int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int taps_w, int64_t H, int64_t oH) {
+int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int taps_w, int64_t H, int64_t oH, int waves_per_cu) {
   const int64_t max_yb = oH / 8 > 1 ? oH / 8 : 1;
   int64_t ybands = 1;
   double best = 1e30;
+  // Wide windows (> 12 taps: rows heavy in arithmetic and staging, 20 halo rows per band): such a kernel reaches its rate with about 12
+  // waves on a CU, so a last (or only) round that fills `sat` of the slots costs no more than its work — and fewer, taller bands save halo
+  // rows.  Measured, config 2 (21-tap bicubic, 24 waves fit a CU), ms by band count: 2: 0.261, 3: 0.229, 4: 0.193, 5: 0.204, 6: 0.206,
+  // 8 (one full round, the old choice): 0.200, 10: 0.218; tolerance mode 4: 0.180, 8: 0.194.  Narrow windows need every wave they can
+  // get to hide memory latency (config A fp32, 26 waves fit: 2 bands 0.310, 10 bands 0.268): sat = 1, the plain round model.
+  const double sat = (taps_w > 12 && waves_per_cu > 12) ? 12.0 / waves_per_cu : 1.0;
   for (int64_t yb = 1; yb <= max_yb && yb <= 64; yb++) {
     const double rounds = (double)items_per_band * yb / slots;
-    const double eff = rounds / ceil(rounds);
+    const double whole = floor(rounds), part = rounds - whole;
+    const double units = whole + (part > 1e-9 ? (part > sat ? part : sat) : 0.0);  // time, in full-occupancy rounds
     const double halo = 1.0 + (double)(yb - 1) * taps_h / (double)H;
-    const double cost = halo / eff;
+    const double cost = halo * units / rounds;
     if (cost < best - 1e-9) {
       best = cost;
       ybands = yb;
@@ -464,6 +471,8 @@ int pick_ybands_f(int64_t items_per_band, double slots, int taps_h, int taps_w, 
   // rounds — shorter work items even out the end of the kernel, and their extra halo rows cost little where the vector ALUs are
   // half idle.  Measured (ms, model | doubled): [256,3,438,906] fp32 NCHW 0.287 | 0.271, channels_last 0.283 | 0.264, [64,3,1024,1024]
   // fp16 bilinear 0.163 | 0.150; the 21-tap bicubic config (vector-ALU bound) loses with more bands (0.20 | 0.22) and keeps the model.
+  // (Round 3 tried to keep the doubling to launches of 1.5 rounds and more — fp16 bilinear 1024 -> 224 prefers 8 bands, 0.102 ms, to its 18,
+  // 0.107 — and lost more elsewhere: fp16 [128,3,438,906] -> (196,320) 0.099 -> 0.110, -> (196,1200) 0.228 -> 0.284.  The rule stays.)
   if (taps_w <= 12 && (double)items_per_band * ybands / slots < 8.0) ybands = 2 * ybands < max_yb ? 2 * ybands : max_yb;
   if (const char *e = aa_knob("AA_FUSED_YBANDS")) {
     const int64_t v = atoll(e);
@@ -499,7 +508,7 @@ int launch_k(FusedF32Params p, const AAProblem &q) {
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
   const int64_t planes = CS == 1 ? q.N * q.C : q.N;
   const int taps_w = q.aw.max_taps > 0 ? q.aw.max_taps : q.aw.ksize;
-  p.ybands = pick_ybands_f(planes * sgroups, (double)aa_device_cu_count() * resident(spb), taps_h, taps_w, q.H, q.oH);
+  p.ybands = pick_ybands_f(planes * sgroups, (double)aa_device_cu_count() * resident(spb), taps_h, taps_w, q.H, q.oH, DT == AA_F32 ? resident(spb) * spb : 0);  // (the saturation model is measured for fp32 only: fp16 bicubic thumbnails lose 20 % with it)
   p.n_groups = planes * (int64_t)p.ybands;
   const int64_t grid = (p.n_groups + 7) / 8 * 8 * sgroups;
   if (grid > 0x7FFFFFFF) return 0;
