@@ -121,20 +121,23 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
 
   p.ybands = 1;
   p.plane_in_bytes = p.plane_out_bytes = 0;
+  p.pl_planes = 0;
 
-  // Plane groups (template parameter PL of the kernel): planar images of three channels, either arithmetic, shrinking heights — one wave
-  // filters the same strip and band of all three planes, sharing each row's staging DMA and fixed work.  The single-plane form keeps every
-  // other planar shape: 1, 2, 4+ channels; growing heights; windows beyond 12 taps (8 in float arithmetic) (the 16-tap instantiation needs 147
-  // VGPRs = 3 waves per SIMD); segments beyond 16 pieces (down-scaling by 4 and more: the single planes' staging DMAs are full enough as
-  // they are, measured +4 % at 1024 -> 224).
-  if (planar && q.C == 3 && !up && tw <= (flt ? 8 : 12) && tw >= 4 && p.nseg <= 16 && G == 8 && q.ah.scatter_max <= 4 && (!q.out_f32 || p.outm == 1) &&
+  // Plane groups (template parameter PL of the kernel): planar bytes, either arithmetic, shrinking heights — one wave filters the same strip
+  // and band of THREE CONSECUTIVE PLANES of the tensor (the channels of an RGB image; three grayscale images; planes of neighbouring
+  // images when C is 2, 4, 5, ...: planes are independent and uniformly spaced), sharing each row's staging DMA and fixed work.  The
+  // single-plane form keeps: growing heights; windows beyond 12 taps (8 in float arithmetic: the wider instantiations need 133-147 VGPRs
+  // = 3 waves per SIMD); segments beyond 16 pieces (down-scaling by 4 and more: the single planes' staging DMAs are full enough as they
+  // are, measured +4 % at 1024 -> 224).
+  if (planar && NI >= 2 && !up && tw <= (flt ? 8 : 12) && tw >= 4 && p.nseg <= 16 && G == 8 && q.ah.scatter_max <= 4 && (!q.out_f32 || p.outm == 1) &&
       3 * p.img_in_bytes <= 0x7FFFFFF0ull && 3 * p.img_out_bytes <= 0x7FFFFFF0ull && g_aa_plane_groups != 0) {
     FusedU8V3Params pg = p;
     pg.plane_in_bytes = p.img_in_bytes;    // (the single-plane form's "images" are the planes)
     pg.plane_out_bytes = p.img_out_bytes;
     pg.img_in_bytes = 3 * p.img_in_bytes;
     pg.img_out_bytes = 3 * p.img_out_bytes;
-    pg.n_images = q.N;
+    pg.n_images = (NI + 2) / 3;  // groups of three consecutive planes (the last one may hold one or two)
+    pg.pl_planes = NI;
     const bool fastg = flt && q.fast;
     pg.fast = fastg ? 1 : 0;
     const size_t lds_g = (size_t)G * 1024;  // (a 1-KiB stage slot per row: the kernel's fixed layout)

@@ -99,6 +99,9 @@ struct FusedU8V3Params {
                    // is not dword aligned: every lane stores its own bytes instead of the quad-merged dword stores
   // plane-group kernels (template parameter PL): bytes between the channel planes of one image, input and output
   unsigned long long plane_in_bytes, plane_out_bytes;
+  long long pl_planes;  // planes of the whole tensor (N * C): a group is PL CONSECUTIVE planes, whatever image they belong to — planes are
+                        // independent and uniformly spaced, so grayscale batches and 2-, 4-, 5-channel planar images group the same way; the
+                        // last group may hold fewer (its missing planes are refused by the range check and never stored)
 };
 
 namespace {
@@ -278,10 +281,12 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   if (out_rem > 0xFFFFFFFFull) out_rem = 0xFFFFFFFFull;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(out + out_off), 0, (unsigned)out_rem, 0x00020000);
   const unsigned out_row_bytes = (unsigned)p.oW * CB;
+  const int pl_valid = PL > 0 ? (int)(p.pl_planes - (long long)n * PL < PL ? p.pl_planes - (long long)n * PL : PL) : C;  // (wave-uniform)
   float nm_mean[C], nm_std[C];  // (float output with normalisation only)
 #pragma unroll
   for (int c = 0; c < C; c++) {
-    const int ch = C == 1 ? (int)(n % (p.cin > 0 ? p.cin : 1)) : c;  // planar input: this wave's plane is channel n % Cin
+    const int ch = PL > 0 ? (int)(((long long)n * PL + c) % (p.cin > 0 ? p.cin : 1))   // plane groups: plane n * PL + c of the tensor
+                          : (C == 1 ? (int)(n % (p.cin > 0 ? p.cin : 1)) : c);      // planar input: this wave's plane is channel n % Cin
     nm_mean[c] = FLT ? p.mean[ch & 3] : 0.f;
     nm_std[c] = FLT ? p.std[ch & 3] : 1.f;
   }
@@ -434,7 +439,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           if constexpr (UPK > 0) vm_issued += C;  // (lane 0 is active: each of the C stores is certainly issued)
 #pragma unroll
           for (int c = 0; c < C; c++)
-            if (active)
+            if (active && (PL == 0 || c < pl_valid))
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[c]), orsrc, (unsigned)(ox0 + lane_o) * 4u,
                                                     ((unsigned)c * (unsigned)p.oH + (unsigned)oy) * (unsigned)p.oW * 4u, AA_V3_F32OUT_AUX);
         } else {
@@ -465,7 +470,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       for (int c = 0; c < C; c++) {
         const unsigned b = FLT ? trunc8(A[0][c]) : (unsigned)clip8_int(A[0][c]);
         if constexpr (PL > 0) {  // (plane c of the image)
-          if (act) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, bv, (unsigned)c * (unsigned)p.plane_out_bytes + (unsigned)oy * out_row_bytes, 0);
+          if (act && c < pl_valid) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, bv, (unsigned)c * (unsigned)p.plane_out_bytes + (unsigned)oy * out_row_bytes, 0);
         } else {
           if (act) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, orsrc, bv + c, (unsigned)oy * out_row_bytes, 0);
         }
@@ -486,7 +491,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
         const unsigned pair = __builtin_amdgcn_perm(nb, t, 0x0c0c0000u | (unsigned)((4 + c) << 8) | (unsigned)c);  // [own c, neighbour c, 0, 0]
         const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pair, 0xAA /*quad_perm:[2,2,2,2]*/, 0xF, 0xF, false);
         const unsigned dw = __builtin_amdgcn_perm(hi, pair, 0x05040100u);
-        if (store_lane) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)c * (unsigned)p.plane_out_bytes + (unsigned)oy * out_row_bytes, 0);
+        if (store_lane && c < pl_valid) __builtin_amdgcn_raw_buffer_store_b32(dw, orsrc, store_voff, (unsigned)c * (unsigned)p.plane_out_bytes + (unsigned)oy * out_row_bytes, 0);
       }
     } else if constexpr (C == 3) {
       const unsigned t = FLT ? (trunc8(A[0][0]) | (trunc8(A[0][1]) << 8) | (trunc8(A[0][2]) << 16))
@@ -676,8 +681,8 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       const int q = p.W - 3 + lane;          // row position of this lane's byte
       const int lpos = q - seg_first;         // ... inside the strip's segment
       if (lane < 3 && q >= 0 && lpos >= 0 && lpos < p.nseg * 16) {
-        const uint8_t b = in[img_off + (unsigned long long)(PL - 1) * p.plane_in_bytes + (unsigned long long)(p.H - 1) * row_bytes + (unsigned)q];
-        lds[lds_base + slot * PL_SLOT + (PL - 1) * PL_PLANE + lpos] = b;
+        const uint8_t b = in[img_off + (unsigned long long)(pl_valid - 1) * p.plane_in_bytes + (unsigned long long)(p.H - 1) * row_bytes + (unsigned)q];
+        lds[lds_base + slot * PL_SLOT + (pl_valid - 1) * PL_PLANE + lpos] = b;  // (the tensor's last plane: the last VALID one of the last group)
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }

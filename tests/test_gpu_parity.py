@@ -967,6 +967,22 @@ def test_plane_groups_equal_single_planes(aa):
                     assert (yf.int() - y0.int()).abs().max().item() <= 1
                 else:
                     torch.testing.assert_close(yf, y0, rtol=1e-4, atol=1e-3)
+        # groups are three CONSECUTIVE planes of the tensor, whatever image they belong to: grayscale batches, 2 / 4 / 5 channels, plane
+        # counts that leave a last group of one or two (whose missing planes are neither read past the tensor nor stored)
+        for shape, out in (((7, 1, 90, 438), (40, 196)), ((4, 1, 64, 300), (30, 132)), ((3, 2, 57, 83), (19, 27)), ((2, 4, 70, 301), (33, 140)),
+                           ((1, 5, 131, 307), (37, 101)), ((1, 1, 50, 60), (20, 24)), ((2, 1, 45, 77), (17, 30))):
+            x = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda")
+            for kw in ({}, {"uint8_mode": "harness"}, {"out_dtype": torch.float32, "mean": [1.0] * shape[1], "std": [2.0, 3.0, 4.0, 5.0, 6.0][:shape[1]]}):
+                if "mean" in kw and shape[1] > 4:
+                    continue
+                _lib.set_plane_groups(1)
+                y1 = aa.linear_forward(x, list(out), **kw)
+                _lib.set_plane_groups(0)
+                y2 = aa.linear_forward(x, list(out), **kw)
+                _lib.set_fused(0)
+                y0 = aa.linear_forward(x, list(out), **kw)
+                _lib.set_fused(1)
+                assert torch.equal(y1, y0) and torch.equal(y2, y0), (shape, out, kw)
         _lib.set_plane_groups(1)
         x = torch.randint(0, 256, (2, 3, 45, 77), dtype=torch.uint8, device="cuda")
         y = aa.linear_forward(x, [17, 30])
