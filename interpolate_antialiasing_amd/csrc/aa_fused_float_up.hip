@@ -95,12 +95,36 @@ __device__ inline float select_by_mask_up(float a, float b, unsigned long long m
   return d;
 }
 
+// 16-bit planes (round 3, template parameter DT): halves are staged and read as halves and converted on the way into the fp32 arithmetic;
+// results are rounded once, at the store (= half(reference_fp32(float(x))), like aa_fused_float.hip); a lane's CPL results leave as one
+// 8-byte store.  The streaming store forms that cut pieces at sector boundaries are fp32-only: 16-bit outputs take the plain forms.
+template <int DT> __device__ inline float up_elem_to_f32(unsigned short bits);
+template <> __device__ inline float up_elem_to_f32<AA_F16>(unsigned short bits) {
+  union { unsigned short u; _Float16 h; } c;
+  c.u = bits;
+  return (float)c.h;
+}
+template <> __device__ inline float up_elem_to_f32<AA_BF16>(unsigned short bits) { return __uint_as_float((unsigned)bits << 16); }
+template <int DT> __device__ inline unsigned up_f32_to_elem(float a);
+template <> __device__ inline unsigned up_f32_to_elem<AA_F16>(float a) {
+  union { unsigned short u; _Float16 h; } c;
+  c.h = (_Float16)a;
+  return c.u;
+}
+template <> __device__ inline unsigned up_f32_to_elem<AA_BF16>(float a) {  // round to nearest even, NaN stays NaN
+  const unsigned u = __float_as_uint(a);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x0040u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
 // U: floats a lane reads per input row (the union of its CPL windows); G: staged rows; KR: vertical taps kept in registers
 // (>= max ysize of the H table); CPL: neighbouring output columns per lane (a strip is 64 * CPL columns).
-template <int U, int G, int KR, int CPL>
+template <int U, int G, int KR, int CPL, int DT = AA_F32>
 __global__ void __launch_bounds__(512)
-fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, const char *__restrict__ tab_w,
+fused_f32_nchw_up_kernel(const void *__restrict__ in, void *__restrict__ out, const char *__restrict__ tab_w,
                          const char *__restrict__ tab_h, const FusedF32UpParams p) {
+  constexpr int ES = DT == AA_F32 ? 4 : 2;  // element bytes
+  constexpr int EPP = 16 / ES;              // elements per staged 16-byte piece
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
   const int lane = threadIdx.x & 63;
@@ -165,15 +189,15 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on vmcnt counts staging DMAs and output stores only
-  const int seg0 = __builtin_amdgcn_readfirstlane(ustart) & ~3;  // lane 0 holds the strip's leftmost window
-  const unsigned lane_lds = (unsigned)(wv * G * p.seg_bytes + (ustart - seg0) * 4);
+  const int seg0 = __builtin_amdgcn_readfirstlane(ustart) & ~(EPP - 1);  // lane 0 holds the strip's leftmost window
+  const unsigned lane_lds = (unsigned)(wv * G * p.seg_bytes + (ustart - seg0) * ES);
 
   const unsigned long long plane_off = (unsigned long long)plane * p.plane_in_bytes;
   unsigned long long remaining = p.total_in_bytes - plane_off;
   if (remaining > 0xFFFFFFFCull) remaining = 0xFFFFFFFCull;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)in + plane_off), 0, (unsigned)remaining, 0x00020000);
-  const unsigned row_bytes = (unsigned)p.W * 4u;
+  const unsigned row_bytes = (unsigned)p.W * (unsigned)ES;
   const int lds_base = wv * G * p.seg_bytes;
   const bool dma_lane = lane < p.nseg;  // nseg <= 64 (checked on the host)
   const unsigned voff = (unsigned)lane * 16u;
@@ -183,12 +207,12 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   if (out_rem > 0xFFFFFFFFull) out_rem = 0xFFFFFFFFull;
   const __amdgpu_buffer_rsrc_t orsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)((uint8_t *)out + out_off), 0, (unsigned)out_rem, 0x00020000);
-  const unsigned out_row_bytes = (unsigned)p.oW * 4u;
-  const unsigned store_voff = (unsigned)(ox0 + col0) * 4u;
+  const unsigned out_row_bytes = (unsigned)p.oW * (unsigned)ES;
+  const unsigned store_voff = (unsigned)(ox0 + col0) * (unsigned)ES;
   const bool full_lane = col0 + CPL <= bw;  // all CPL columns of the lane exist: one wide store
   const unsigned phase0 = (unsigned)(((unsigned long long)(uintptr_t)out + out_off + (unsigned long long)ox0 * 4u) & 127u);
 
-  const unsigned a_base = (unsigned)seg0 * 4u;  // byte offset (from the plane) of the strip's segment in row 0
+  const unsigned a_base = (unsigned)seg0 * (unsigned)ES;  // byte offset (from the plane) of the strip's segment in row 0
   // sector-aligned pieces: this wave's 1088-byte staging area behind the workgroup's stage rings; float phase of the plane in
   // the 64-byte sector grid
   const unsigned aln_lds = (unsigned)(p.strips_per_block * G * p.seg_bytes + wv * 1088);
@@ -223,14 +247,35 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
   int slot_top = 0;
 
   // one input row: wait for its DMA, union window from LDS, reference-order accumulation per output, refill, push
+  // 16-bit elements, odd W: the dword holding the tensor's final element straddles the end of the tensor and is refused by the range
+  // check (see aa_fused_float.hip: nothing may be read past a tensor); lane 0 fetches that element on its own into the staged row
+  const int fix_row = (ES == 2 && (p.W & 1) && (long long)plane + 1 == p.n_groups / p.ybands) ? p.H - 1 : -1;
   auto hpass_row = [&]() {
     const int my_idx = __builtin_amdgcn_readlane(idxv, slot_top);
     wait_vmcnt_up(vm_issued - my_idx);  // everything issued up to and including that DMA has completed
-    const __attribute__((address_space(3))) float *src =
-        (const __attribute__((address_space(3))) float *)(uintptr_t)(lane_lds + (unsigned)(slot_top * p.seg_bytes));
+    if (ES == 2 && top == fix_row) {
+      const int pos = p.W - 1 - seg0;  // (even: seg0 is a multiple of 8, W is odd)
+      if (pos >= 0 && pos < p.nseg * EPP) {
+        if (lane == 0) {
+          const unsigned short v = *(const unsigned short *)((const uint8_t *)in + plane_off + (unsigned long long)(p.H - 1) * row_bytes +
+                                                             (unsigned long long)(p.W - 1) * 2u);
+          *(unsigned *)(lds + lds_base + slot_top * p.seg_bytes + pos * 2) = (unsigned)v;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+    }
     float d[U];
+    if constexpr (DT == AA_F32) {
+      const __attribute__((address_space(3))) float *src =
+          (const __attribute__((address_space(3))) float *)(uintptr_t)(lane_lds + (unsigned)(slot_top * p.seg_bytes));
 #pragma unroll
-    for (int q = 0; q < U; q++) d[q] = src[q];
+      for (int q = 0; q < U; q++) d[q] = src[q];
+    } else {
+      const __attribute__((address_space(3))) unsigned short *src =
+          (const __attribute__((address_space(3))) unsigned short *)(uintptr_t)(lane_lds + (unsigned)(slot_top * p.seg_bytes));
+#pragma unroll
+      for (int q = 0; q < U; q++) d[q] = up_elem_to_f32<DT>(src[q]);
+    }
     float acc[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; e++) {
@@ -305,6 +350,42 @@ fused_f32_nchw_up_kernel(const float *__restrict__ in, float *__restrict__ out, 
     const unsigned soff = AA_UP_ABL == 3 ? 0u : (unsigned)oy * out_row_bytes;
     // vm_issued may only count instructions that are certainly issued (an all-lanes-off store is branched around): every
     // count below is guarded by a wave-uniform condition under which lane 0 or the ragged lane really stores
+    if constexpr (DT != AA_F32) {  // 16-bit planes: one store of the lane's CPL halves (plain or streaming), ragged columns one by one
+      unsigned hb[CPL];
+#pragma unroll
+      for (int e = 0; e < CPL; e++) hb[e] = up_f32_to_elem<DT>(res[e]);
+      if constexpr (CPL == 4) {
+        typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
+        const u32x2h t = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+        if (bw >= CPL) {
+          if (full_lane) {
+            if (p.store_nt != 0) __builtin_amdgcn_raw_buffer_store_b64(t, orsrc, store_voff, soff, 2);
+            else __builtin_amdgcn_raw_buffer_store_b64(t, orsrc, store_voff, soff, 0);
+          }
+          vm_issued++;
+        }
+      } else if constexpr (CPL == 2) {
+        if (bw >= CPL) {
+          if (full_lane) __builtin_amdgcn_raw_buffer_store_b32(hb[0] | (hb[1] << 16), orsrc, store_voff, soff, 0);
+          vm_issued++;
+        }
+      } else {
+        if (any_active) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)hb[0], orsrc, store_voff, soff, 0);
+        vm_issued++;
+      }
+      if constexpr (CPL > 1) {
+        const int ragged = bw % CPL;
+#pragma unroll
+        for (int e = 0; e < CPL - 1; e++) {
+          if (__builtin_expect(ragged != 0, 0) && e < ragged) {
+            if (col0 == bw - ragged) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)hb[e], orsrc, store_voff + 2u * e, soff, 0);
+            vm_issued++;
+          }
+        }
+      }
+      cur = nxt;
+      continue;
+    }
     if constexpr (CPL == 4) {
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const u32x4 t = {__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2]), __float_as_uint(res[3])};
@@ -423,9 +504,9 @@ int pick_ybands_up(int64_t items_per_band, int waves_per_item, double slots, int
   return (int)ybands;
 }
 
-template <int U, int G, int KR, int CPL>
+template <int U, int G, int KR, int CPL, int DT>
 int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
-  auto kern = fused_f32_nchw_up_kernel<U, G, KR, CPL>;
+  auto kern = fused_f32_nchw_up_kernel<U, G, KR, CPL, DT>;
   auto resident = [&](int s) {  // workgroups of s strips a CU holds (-1: their rings do not fit a workgroup's LDS)
     if (lds * s > 64 * 1024) return -1;  // (never for s == 1: a strip's ring is at most 8 KiB)
     int nb = aa_resident_blocks(kern, 64 * s, lds * s);
@@ -455,24 +536,24 @@ int launch_k(FusedF32UpParams p, const AAProblem &q, size_t lds) {
   if (aa_knob("AA_UP_DEBUG"))
     fprintf(stderr, "up: U=%d KR=%d CPL=%d nstrips=%d spb=%d resident=%d ybands=%d groups=%lld grid=%lld lds=%zu nt=%d\n", U, KR, CPL, p.nstrips, spb,
             resident(spb), p.ybands, (long long)p.n_groups, (long long)grid, lds_blk, p.store_nt);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, (const float *)q.in, (float *)q.out,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * spb), lds_blk, q.stream, (const void *)q.in, (void *)q.out,
                      (const char *)q.aw.table_dev, (const char *)q.ah.table_dev, p);
   AA_HIP_CHECK_LAUNCH();
   return 1;
 }
 
-template <int U, int CPL>
+template <int U, int CPL, int DT>
 int launch_kr(int kr, const FusedF32UpParams &p, const AAProblem &q, size_t lds) {
-  if (kr <= 2) return launch_k<U, AA_UP_G, 2, CPL>(p, q, lds);
-  if (kr <= 4) return launch_k<U, AA_UP_G, 4, CPL>(p, q, lds);
-  return launch_k<U, AA_UP_G, 6, CPL>(p, q, lds);
+  if (kr <= 2) return launch_k<U, AA_UP_G, 2, CPL, DT>(p, q, lds);
+  if (kr <= 4) return launch_k<U, AA_UP_G, 4, CPL, DT>(p, q, lds);
+  return launch_k<U, AA_UP_G, 6, CPL, DT>(p, q, lds);
 }
 
 // Columns per lane and union width: the widest CPL whose CPL * U lane masks fit the scalar registers (<= 20) and whose
 // strip segment is one DMA instruction (<= 64 pieces); U = taps + spread of CPL neighbouring window starts.
 struct UpGeometry { int cpl, u, nstrips, strip_w, nseg; };
 
-bool up_geometry(int64_t W, const aa_axis &aw, UpGeometry *g) {
+bool up_geometry(int64_t W, const aa_axis &aw, UpGeometry *g, int es = 4) {
   const int taps_w = aw.max_taps > 0 ? aw.max_taps : aw.ksize;
   if (taps_w > 8 || aw.span64p1 <= 0 || aw.span4p1 <= 0) return false;
   const int64_t oW = aw.out_size;
@@ -489,8 +570,8 @@ bool up_geometry(int64_t W, const aa_axis &aw, UpGeometry *g) {
       if (u <= o) { uu = o; break; }
     if (uu == 0 || uu * cpl > 20 || W < uu) continue;
     // floats a strip of 64 * cpl outputs covers: cpl * spread of 64 starts (+3: rounded down to a multiple of 4) + union
-    const int span = cpl * (aw.span64p1 - 1) + cpl + uu + 3;
-    const int nseg = (span * 4 + 15) / 16 + 1;
+    const int span = cpl * (aw.span64p1 - 1) + cpl + uu + (16 / es - 1);  // (+: the segment start rounded down to a 16-byte piece of the row)
+    const int nseg = (span * es + 15) / 16 + 1;
     if (nseg > 64) continue;
     g->cpl = cpl; g->u = uu; g->nseg = nseg;
     g->strip_w = 64 * cpl;
@@ -504,13 +585,14 @@ bool up_geometry(int64_t W, const aa_axis &aw, UpGeometry *g) {
 
 bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t N, int64_t C, int64_t H, int64_t W, const aa_axis *ah,
                                        const aa_axis *aw) {
-  if (dtype != AA_F32 || layout != AA_NCHW) return false;
+  if ((dtype != AA_F32 && dtype != AA_F16 && dtype != AA_BF16) || layout != AA_NCHW) return false;
   if (!ah || !aw || ah->kind != AA_TABLE_F32 || aw->kind != AA_TABLE_F32) return false;
+  const int es = dtype == AA_F32 ? 4 : 2;
   if (H > ah->out_size) return false;  // shrinking heights: aa_fused_float.hip
   const int taps_h = ah->max_taps > 0 ? ah->max_taps : ah->ksize;
   if (taps_h > 6 || ah->gather_off <= 0) return false;  // (a gather record holds 6 weights)
   UpGeometry g;
-  if (!up_geometry(W, *aw, &g)) return false;
+  if (!up_geometry(W, *aw, &g, es)) return false;
   if ((uint64_t)H * W * 4 > 0xFFFFFFF0ull || (uint64_t)ah->out_size * aw->out_size * 4 > 0xFFFFFFF0ull) return false;
   if (!aa_grid_fits(N * C * g.nstrips)) return false;
   return true;
@@ -519,15 +601,16 @@ bool aa_fused_float_nchw_up_applicable(int dtype, int layout, int64_t N, int64_t
 int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   if (!aa_fused_float_nchw_up_applicable(q.dtype, q.layout, q.N, q.C, q.H, q.W, &q.ah, &q.aw)) return 0;
   const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
-  if (((uintptr_t)q.out & 3) != 0 || ((uintptr_t)q.in & 3) != 0) return 0;
+  const int es = q.dtype == AA_F32 ? 4 : 2;
+  if (((uintptr_t)q.out & (es - 1)) != 0 || ((uintptr_t)q.in & (es - 1)) != 0) return 0;
   UpGeometry g;
-  up_geometry(q.W, q.aw, &g);
+  up_geometry(q.W, q.aw, &g, es);
 
   FusedF32UpParams p;
   p.H = (int)q.H; p.W = (int)q.W; p.oH = (int)q.oH; p.oW = (int)q.oW;
   p.ksize_w = q.aw.ksize; p.ksize_h = q.ah.ksize;
-  p.plane_in_bytes = (unsigned long long)q.H * q.W * 4;
-  p.plane_out_bytes = (unsigned long long)q.oH * q.oW * 4;
+  p.plane_in_bytes = (unsigned long long)q.H * q.W * es;
+  p.plane_out_bytes = (unsigned long long)q.oH * q.oW * es;
   p.total_in_bytes = p.plane_in_bytes * (unsigned long long)(q.N * q.C);
   p.total_out_bytes = p.plane_out_bytes * (unsigned long long)(q.N * q.C);
   p.nstrips = g.nstrips;
@@ -539,7 +622,7 @@ int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   p.store_nt = g_aa_store_form < 0 ? (p.total_out_bytes > (64ull << 20) ? 1 : 0) : (g_aa_store_form ? 1 : 0);  // (aa_set_store_form: tests of the
                                                                                                                // streaming forms at small sizes)
   // rows or planes that are not whole 64-byte sectors: stream only the whole sectors of each piece (see the store)
-  if (p.store_nt && g.cpl == 4 && ((((uintptr_t)q.out) | (uint64_t)q.oW * 4u | p.plane_out_bytes) & 63u) != 0 && !aa_knob("AA_UP_NO_SPLIT"))
+  if (es == 4 && p.store_nt && g.cpl == 4 && ((((uintptr_t)q.out) | (uint64_t)q.oW * 4u | p.plane_out_bytes) & 63u) != 0 && !aa_knob("AA_UP_NO_SPLIT"))
     p.store_nt = 2;
   // ... and when the rows are 8-byte but not 16-byte aligned (oW = 906): strips cut at the sector boundaries of each row instead
   // (see the store).  Measured, [256,3,196,320] gradients -> 438 x W (ms, split + pacing | sector-aligned pieces): W = 898 0.347 | 0.312,
@@ -556,11 +639,15 @@ int aa_try_fused_float_nchw_up(const AAProblem &q, const char **variant) {
   const size_t lds = (size_t)AA_UP_G * p.seg_bytes + (p.store_nt == 3 ? 1088 : 0);  // per strip: stage ring (+ the aligned-store staging area)
 
   int rc = 0;
-#define AA_UP_CASE(UU, CC) if (g.u == UU && g.cpl == CC) rc = launch_kr<UU, CC>(taps_h, p, q, lds)
+#define AA_UP_CASE(UU, CC)                                                                     \
+  if (g.u == UU && g.cpl == CC)                                                                \
+    rc = q.dtype == AA_F32 ? launch_kr<UU, CC, AA_F32>(taps_h, p, q, lds)                      \
+                           : (q.dtype == AA_F16 ? launch_kr<UU, CC, AA_F16>(taps_h, p, q, lds) \
+                                                : launch_kr<UU, CC, AA_BF16>(taps_h, p, q, lds))
   AA_UP_CASE(2, 4); else AA_UP_CASE(3, 4); else AA_UP_CASE(4, 4); else AA_UP_CASE(5, 4);
   else AA_UP_CASE(2, 2); else AA_UP_CASE(3, 2); else AA_UP_CASE(4, 2); else AA_UP_CASE(5, 2); else AA_UP_CASE(6, 2); else AA_UP_CASE(8, 2);
   else AA_UP_CASE(2, 1); else AA_UP_CASE(3, 1); else AA_UP_CASE(4, 1); else AA_UP_CASE(5, 1); else AA_UP_CASE(6, 1); else AA_UP_CASE(8, 1);
 #undef AA_UP_CASE
-  if (rc == 1) *variant = "fused_f32_nchw_up";
+  if (rc == 1) *variant = q.dtype == AA_F32 ? "fused_f32_nchw_up" : (q.dtype == AA_F16 ? "fused_f16_nchw_up" : "fused_bf16_nchw_up");
   return rc;
 }

@@ -1085,6 +1085,38 @@ def test_fp16_products_are_the_references(aa):
         torch.testing.assert_close(yf.float()[ok], y0.float()[ok], rtol=2e-3, atol=1e-3)
 
 
+def test_sixteen_bit_growing_heights_are_fused(aa):
+    """fp16 / bf16 planes whose height does not shrink (test.py's 1200 x 1200 and (1200, 196)-like sizes in halves): the up-scaling kernel
+    stages and reads halves, computes in fp32 and rounds once at the store (round 3; these shapes ran two launches).  Bit-identical to the
+    two-launch path and to half(oracle_fp32(float(x))): 4 / 2 / 1 columns per lane, ragged widths, odd W (the tensor's final element is
+    fetched on its own: nothing is read past the tensor), plain and streaming store forms."""
+    from interpolate_antialiasing_amd import _lib
+
+    torch.manual_seed(8)
+    for dt, name in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        for shape, size, filt in (((2, 3, 64, 120), (150, 300), "linear"), ((2, 3, 64, 121), (150, 301), "cubic"), ((1, 2, 33, 19), (70, 50), "linear"),
+                                  ((3, 1, 40, 57), (44, 130), "cubic"), ((2, 3, 100, 200), (240, 203), "linear"), ((1, 3, 438, 906), (1200, 1200), "linear"),
+                                  ((2, 4, 32, 512), (96, 512), "linear")):   # (a 19 x 512-byte-class tensor: ends on its allocation)
+            x = ((torch.rand(*shape, device="cuda") * 300) - 40).to(dt)
+            fn = _fn(aa, filt)
+            for form in (-1, 1):
+                prev = _lib.set_store_form(form)
+                try:
+                    y = fn(x, list(size))
+                    v = _lib.last_variant()
+                    _lib.set_fused(0)
+                    y0 = fn(x, list(size))
+                finally:
+                    _lib.set_fused(1)
+                    _lib.set_store_form(prev)
+                assert v == f"fused_{name}_nchw_up", (name, shape, size, v)
+                assert torch.equal(y.view(torch.int16), y0.view(torch.int16)), (name, shape, size, filt, form)
+        x = ((torch.rand(1, 2, 30, 41, device="cuda") * 300) - 40).to(dt)
+        y = aa.linear_forward(x, [70, 90])
+        exp = torch.from_numpy(oracle.forward("linear", x.float().cpu().numpy(), (70, 90))).to(dt)
+        assert torch.equal(y.cpu().view(torch.int16), exp.view(torch.int16)), name
+
+
 def test_sixteen_bit_tensor_ending_on_its_allocation(aa):
     """Rows of 16-bit elements with an odd W: the dword that holds the tensor's final element straddles the end of the tensor.  The
     fused kernel must neither drop that element nor read the two bytes beyond it (round 3: the second form faulted once in 90 000
