@@ -133,6 +133,12 @@ inline int aa_strip_span_px32(const aa_axis &aw, int tw) {
   const int by4 = 11 * (aw.span4p1 - 1) + 1;
   return (by4 < aw.span64p1 ? by4 : aw.span64p1) + tw;
 }
+// ... and for a strip of 16 outputs (split windows: four lanes per pixel): 15 steps are 5 runs of 3
+inline int aa_strip_span_px16(const aa_axis &aw, int tw) {
+  if (aw.span64p1 <= 0 || aw.span4p1 <= 0) return -1;
+  const int by4 = 5 * (aw.span4p1 - 1) + 1;
+  return (by4 < aw.span64p1 ? by4 : aw.span64p1) + tw;
+}
 // (row bands never exceed 64, so a grid of `units * 64` workgroups bounds every launch)
 inline bool aa_grid_fits(int64_t units) { return units > 0 && units <= (int64_t)0x7FFFFFFF / 64 - 8; }
 // CU count of the current device (cached); 256 on MI355X

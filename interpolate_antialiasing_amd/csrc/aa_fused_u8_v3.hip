@@ -36,12 +36,17 @@ static bool v3_shape_ok(int dtype, int layout, int64_t N, int64_t Cin, int64_t H
   // windows of 17 .. 34 taps: Pillow arithmetic, shrinking heights.  (With growing heights — test.py's (120, 1200) — the gather form with
   // such windows was built and measured SLOWER than the two-launch path: bicubic channels_last 0.226 vs 0.205 ms per 128 images.)
   if (tw > 16 && up) return false;
-  if (tw == 0 || W < tw) return false;
+  // windows of 35 .. 136 taps (down-scaling by 17 .. 68 bilinear, 9 .. 34 bicubic): SPLIT windows — four lanes share an output pixel, each
+  // holds a quarter of its window (tw = taps per lane: 16 / 24 / 34) and the partial sums meet in two DPP additions; Pillow arithmetic
+  // (integer sums are associative: bit-exact), shrinking heights, uint8 out; strips of 16 columns
+  const bool split = tw == 0 && taps_w <= 136 && !flt && !up && !out_f32;
+  if (split) tw = taps_w <= 64 ? 16 : (taps_w <= 96 ? 24 : 34);
+  if (tw == 0 || W < (split ? 4 * tw : tw)) return false;
   if ((uint64_t)H * W * C > 0x7FFFFFF0ull || (uint64_t)oH * oW * C > 0xFFFFFFF0ull) return false;
-  int span_px = aa_strip_span_px(aw, tw);
+  int span_px = split ? aa_strip_span_px16(aw, 4 * tw) : aa_strip_span_px(aw, tw);
   if (span_px < 0) return false;
   int nseg = (span_px * C + 3 + 15 + 15) / 16;
-  int cap = 64;  // output columns per strip
+  int cap = split ? 16 : 64;  // output columns per strip
   if (up && nseg > 64) {
     // the gather form is instantiated with one staging DMA per row (64 pieces): strong down-scaling in W (test.py's 906 -> 120
     // with growing heights) gets strips of 32 columns — half the lanes idle, but such a shape is bound by its input stream
@@ -112,7 +117,8 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   }
 
   // segment: bytes covered by 64 consecutive windows of one input row (+ alignment slack), see aa_fused_u8_v2.hip
-  const int span_px = cap == 32 ? aa_strip_span_px32(q.aw, tw) : aa_strip_span_px(q.aw, tw);
+  const bool split = cap == 16;  // (v3_shape_ok: four lanes per output pixel, tw taps each)
+  const int span_px = split ? aa_strip_span_px16(q.aw, 4 * tw) : (cap == 32 ? aa_strip_span_px32(q.aw, tw) : aa_strip_span_px(q.aw, tw));
   p.nseg = (span_px * C + 3 + 15 + 15) / 16;
   if (p.nseg > 128) return 0;
   p.seg_bytes = p.nseg * 16;
@@ -153,7 +159,11 @@ int aa_try_fused_u8_nhwc_v3(const AAProblem &q, const char **variant) {
   }
 
   int rc;
-  if (up) {
+  if (split) {
+    p.byte_store = 1;  // (a quad's first lane stores its pixel's bytes)
+    rc = C == 3 ? aa_v3_launch_c3s(tw, q.ah.scatter_max, p, q, lds) : C == 4 ? aa_v3_launch_c4s(tw, q.ah.scatter_max, p, q, lds)
+                                                                             : aa_v3_launch_c1s(tw, q.ah.scatter_max, p, q, lds);
+  } else if (up) {
     const int taps_h = q.ah.max_taps > 0 ? q.ah.max_taps : q.ah.ksize;
     const bool nonneg = q.aw.filter != AA_FILTER_CUBIC && q.ah.filter != AA_FILTER_CUBIC;
     rc = C == 3   ? aa_v3_launch_up_c3(tw, taps_h, nonneg, flt, p, q, lds)

@@ -176,11 +176,17 @@ __device__ inline void wait_vmcnt(int n) {  // rounding n DOWN only waits longer
 //     arithmetic: Pillow's integers, or FLT = the harness's floats with uint8 or float32 planes out);
 //     vertical pass and accumulators as for C interleaved channels; one 64-byte row piece stored per plane.  Pillow arithmetic,
 //     shrinking heights.
-template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0, int PL = 0>
+// SP: split windows — SP = 4 LANES share one output pixel, each holding a quarter (TW taps) of its window; the four partial sums meet in two
+//     DPP additions (quad_perm [1,0,3,2], then [2,3,0,1]), after which every lane of the quad holds the pixel's horizontal-pass result and
+//     runs the vertical pass redundantly.  Integer sums are associative, so the result is Pillow's bit for bit whatever the split.  This is
+//     the form for windows beyond what one lane's registers hold (35 .. 136 taps: down-scaling by 17 .. 68 bilinear, 9 .. 34 bicubic); a
+//     strip is 16 columns, stored bytewise by each quad's first lane (outputs are tiny at such scales).
+template <int C, int TW, int G, bool TWO_DMA, int MAXC, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0, int PL = 0, int SP = 1>
 __global__ void __launch_bounds__(512) AA_V3_OCC
 fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const char *__restrict__ tab_w,
                         const char *__restrict__ tab_h, const FusedU8V3Params p) {
   static_assert(PL == 0 || (PL == C && !PERIODIC && UPK == 0 && !TWO_DMA), "plane groups: shrinking heights, fixed stage layout");
+  static_assert(SP == 1 || (SP == 4 && !FLT && !PERIODIC && UPK == 0 && PL == 0), "split windows: integer arithmetic, shrinking heights");
   constexpr int PLN = PL > 0 ? PL : 1;  // windows per lane and row
   constexpr int CB = PL > 0 ? 1 : C;    // bytes per pixel in a staged row
   constexpr int NV1 = (CB * TW + 3) / 4;  // dwords holding one window
@@ -232,18 +238,21 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
   const int n_groups = (n_rows + G - 1) / G;
 
   // ---- per-lane horizontal-pass state ------------------------------------------------------------------------
-  const bool active = lane < bw;
-  const int ox = ox0 + (active ? lane : 0);
+  const int sp_px = SP > 1 ? lane / SP : lane;    // the lane's pixel of the strip
+  const int sp_part = SP > 1 ? lane % SP : 0;     // ... and its quarter of that pixel's window
+  const bool active = sp_px < bw;
+  const int ox = ox0 + (active ? sp_px : 0);
   const int xm = xmin_w[ox];
   int xs = xsize_w[ox];
   xs = xs > 1 ? xs : 1;
-  int lead = xm + TW - p.W;  // right-align windows whose zero-weight padding would leave the row
+  int lead = xm + TW * SP - p.W;  // right-align windows whose zero-weight padding would leave the row
   lead = lead > 0 ? lead : 0;
-  const int start = xm - lead;
+  const int start = xm - lead + sp_part * TW;
+  const int acc_init = (SP > 1 && sp_part != 0) ? 0 : 1 << 21;  // (split windows: Pillow's rounding constant enters once per pixel)
   int wreg[TW];
 #pragma unroll
   for (int j = 0; j < TW; j++) {
-    const int src = j - lead;
+    const int src = sp_part * TW + j - lead;
     int w = (src >= 0 && src < xs && src < p.ksize_w) ? kw[(size_t)ox * p.ksize_w + src] : 0;
     wreg[j] = FLT ? w : (w << 8) >> 8;  // 24-bit operand for v_mul_i32_i24 (FLT: the float's bit pattern, 0 = +0.0f)
   }
@@ -463,8 +472,9 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));  // keep this rare path's address arithmetic INSIDE it: hoisted out of the row loop it
                                         // costs the common path 5 VGPRs, i.e. a wave per SIMD (76 -> 81 registers)
-      const unsigned bv = (unsigned)((ox0 + lane_o) * CB);
-      const bool act = lane_o < bw;
+      const int px_o = SP > 1 ? lane_o / SP : lane_o;  // (split windows: the quad's first lane stores the pixel)
+      const unsigned bv = (unsigned)((ox0 + px_o) * CB);
+      const bool act = px_o < bw && (SP == 1 || (lane_o % SP) == 0);
       if constexpr (UPK > 0) vm_issued += C;
 #pragma unroll
       for (int c = 0; c < C; c++) {
@@ -577,7 +587,7 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     } else {
       int acc[C];
 #pragma unroll
-      for (int c = 0; c < C; c++) acc[c] = AA_V3_ABL == 5 ? (int)v[c] : 1 << 21;
+      for (int c = 0; c < C; c++) acc[c] = AA_V3_ABL == 5 ? (int)v[c] : (SP > 1 ? acc_init : 1 << 21);
 #pragma unroll
       for (int j = 0; j < (AA_V3_ABL == 5 ? 0 : TW); j++) {
 #pragma unroll
@@ -585,6 +595,13 @@ fused_u8_nhwc_v3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
           const int bi = PL > 0 ? c * (4 * NV1) + j : j * C + c;  // (plane groups: channel c's own window)
           const int px = (int)((v[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
           acc[c] += px * wreg[j];
+        }
+      }
+      if constexpr (SP > 1) {  // the quad's four partial sums: after two exchanges every lane holds their total
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          acc[c] += __builtin_amdgcn_update_dpp(0, acc[c], 0xB1 /*quad_perm:[1,0,3,2]*/, 0xF, 0xF, false);
+          acc[c] += __builtin_amdgcn_update_dpp(0, acc[c], 0x4E /*quad_perm:[2,3,0,1]*/, 0xF, 0xF, false);
         }
       }
 #pragma unroll
@@ -813,9 +830,9 @@ int pick_ybands(int64_t items_per_band, double slots, int taps_h, int64_t H, int
   return (int)ybands;
 }
 
-template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0, int PL = 0>
+template <int C, int TW, int G, int MAXC, bool TWO, bool NONNEG, bool PERIODIC, bool FLT = false, int UPK = 0, int PL = 0, int SP = 1>
 int launch_k(FusedU8V3Params p, const AAProblem &q, size_t lds, int64_t) {
-  auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC, FLT, UPK, PL>;
+  auto kern = fused_u8_nhwc_v3_kernel<C, TW, G, TWO, MAXC, NONNEG, PERIODIC, FLT, UPK, PL, SP>;
   auto resident = [&](int s) {  // resident workgroups of s strips per CU for this instantiation and this problem's LDS
     int nb = aa_resident_blocks(kern, 64 * s, lds * s);
     if (nb <= 0) nb = 16 / s;
@@ -951,6 +968,29 @@ int dispatch_tw_wide_flt(int tw, int maxc, const FusedU8V3Params &p, const AAPro
   return 0;
 }
 
+// split windows (template parameter SP): 35 .. 136 taps, four lanes per output pixel; instantiated in aa_fused_u8_v3_c{1,3,4}s.hip
+template <int C, int TW, int MAXC>
+int launch_split_m(const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  const bool nonneg = q.aw.filter != AA_FILTER_CUBIC && q.ah.filter != AA_FILTER_CUBIC;
+  if (p.nseg > 64)
+    return nonneg ? launch_k<C, TW, 8, MAXC, true, true, false, false, 0, 0, 4>(p, q, lds, 0) : launch_k<C, TW, 8, MAXC, true, false, false, false, 0, 0, 4>(p, q, lds, 0);
+  return nonneg ? launch_k<C, TW, 8, MAXC, false, true, false, false, 0, 0, 4>(p, q, lds, 0) : launch_k<C, TW, 8, MAXC, false, false, false, false, 0, 0, 4>(p, q, lds, 0);
+}
+template <int C, int TW>
+int launch_split(int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {
+  if (maxc <= 2) return launch_split_m<C, TW, 2>(p, q, lds);
+  if (maxc <= 3) return launch_split_m<C, TW, 3>(p, q, lds);
+  if (maxc <= 4) return launch_split_m<C, TW, 4>(p, q, lds);
+  return launch_split_m<C, TW, 6>(p, q, lds);
+}
+template <int C>
+int dispatch_tw_split(int tws, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds) {  // tws: taps per LANE
+  if (tws <= 16) return launch_split<C, 16>(maxc, p, q, lds);
+  if (tws <= 24) return launch_split<C, 24>(maxc, p, q, lds);
+  if (tws <= 34) return launch_split<C, 34>(maxc, p, q, lds);
+  return 0;
+}
+
 // plane groups (template parameter PL): the three planes of a planar image in one wave; instantiated in aa_fused_u8_v3_c3g.hip
 // (templates over the plane count so that only the translation units that name them instantiate the kernels)
 template <int PLANES, int TW>
@@ -1041,6 +1081,10 @@ int aa_v3_launch_c3gff(int tw, int maxc, const FusedU8V3Params &p, const AAProbl
 int aa_v3_launch_c1wf(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c3wf(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_c4wf(int tw, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+// split windows, 35 .. 136 taps (aa_fused_u8_v3_c{1,3,4}s.hip)
+int aa_v3_launch_c1s(int tws, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c3s(int tws, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
+int aa_v3_launch_c4s(int tws, int maxc, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 // growing heights (aa_fused_u8_v3_c{1,3,4}u.hip)
 int aa_v3_launch_up_c1(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);
 int aa_v3_launch_up_c3(int tw, int upk, bool nonneg, bool flt, const FusedU8V3Params &p, const AAProblem &q, size_t lds);

@@ -825,7 +825,8 @@ def test_workspace_answer_matches_dispatch(aa):
                                   (aa.linear_forward, (1, 300, 2400, 3), [50, 400], "fused_u8_nhwc_pil_v3"),      # 13 taps
                                   (aa.linear_forward, (1, 2400, 2400, 3), [400, 400], "fused_u8_nhwc_pil_v3"),
                                   (aa.cubic_forward, (1, 700, 1400, 4), [100, 200], "fused_u8_nhwc_pil_v3"),     # 29 taps: the 34-tap window (round 3)
-                                  (aa.cubic_forward, (1, 700, 1400, 4), [100, 100], "generic_2pass_u8_pil")):      # 57 taps: no fused kernel
+                                  (aa.cubic_forward, (1, 700, 1400, 4), [100, 100], "fused_u8_nhwc_pil_v3"),     # 57 taps: split windows, four lanes per pixel (round 3)
+                                  (aa.cubic_forward, (1, 700, 1400, 4), [100, 38], "generic_2pass_u8_pil")):      # 149 taps: no fused kernel
         x = torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda").permute(0, 3, 1, 2)
         y = fn(x, size)
         v = _lib.last_variant()
@@ -1216,6 +1217,37 @@ def test_fuzz_fused_equals_generic(aa):
     assert fused >= 45 * cases // 120, fused  # about half of the random problems take a fused kernel (the rest: C = 2 or 5, fp64 channels_last, ...)
 
 
+def test_fuzz_strong_downscales(aa):
+    """80 seeded random STRONG down-scales of uint8 images in Pillow arithmetic (widths shrinking 7 .. 45 times: 17 .. 180 taps): the
+    wide-window, split-window (four lanes per pixel, DPP reduction) and generic forms must all give the two-launch path's bytes; 1, 3, 4
+    channels, both layouts, ragged sizes, windows clipped at both borders."""
+    from interpolate_antialiasing_amd import _lib
+
+    rng = np.random.default_rng(31415)
+    seen = set()
+    for it in range(80):
+        c = int(rng.choice([1, 3, 3, 4]))
+        n = int(rng.integers(1, 4))
+        h, w = int(rng.integers(40, 500)), int(rng.integers(200, 2000))
+        ow = max(1, int(w / rng.uniform(7.0, 45.0)))
+        oh = max(1, int(h / rng.uniform(1.0, 12.0)))
+        filt = ["linear", "cubic"][int(rng.integers(2))]
+        x = torch.randint(0, 256, (n, c, h, w), dtype=torch.uint8, device="cuda")
+        if bool(rng.integers(2)):
+            x = x.contiguous(memory_format=torch.channels_last)
+        fn = _fn(aa, filt)
+        try:
+            _lib.set_fused(1)
+            y1 = fn(x, [oh, ow])
+            seen.add(_lib.last_variant())
+            _lib.set_fused(0)
+            y0 = fn(x, [oh, ow])
+        finally:
+            _lib.set_fused(1)
+        assert torch.equal(y1, y0), (it, c, (n, h, w), (oh, ow), filt, _lib.last_variant())
+    assert {"fused_u8_nhwc_pil_v3", "fused_u8_planar_pil_v3"} <= seen, seen
+
+
 def test_fuzz_vs_oracle_small(aa):
     """80 seeded random small problems straight against the oracle (bit-exact): fp32 / fp64 forward in both layouts, uint8 in Pillow
     and harness arithmetic, including sizes of 1, up-scales and windows clipped at both borders."""
@@ -1529,10 +1561,28 @@ def test_wide_windows_take_the_fused_uint8_kernel(aa, golden_kat):
         yf = _fn(aa, filt)(xf, list(size), precision="fast")
         assert _lib.last_variant() == "fused_f32_nchw_fast"
         np.testing.assert_allclose(yf.cpu().numpy(), y.cpu().numpy(), rtol=1e-4, atol=1e-4 * 255)
-    # beyond 34 taps (or more than 6 open rows): still the generic path
-    y = aa.cubic_forward(x_hwc.permute(0, 3, 1, 2), [40, 40])
+    # beyond 34 taps: SPLIT windows (round 3) — four lanes share an output pixel, each holds a quarter of its window, the partial sums meet
+    # in two DPP additions (BASELINE north_star's "wavefront shuffles to reduce the variable-width filter tap accumulation"): integer sums
+    # are associative, so Pillow's result bit for bit.  35 .. 136 taps, 16 / 24 / 34 taps per lane, channels_last and planar.
+    for filt, size in (("cubic", (40, 40)), ("linear", (20, 30)), ("cubic", (33, 61)), ("linear", (12, 30)), ("cubic", (100, 28)), ("linear", (196, 26))):
+        for planar in (False, True):
+            x = x_hwc.permute(0, 3, 1, 2)
+            x = x.contiguous() if planar else x
+            try:
+                _lib.set_fused(1)
+                y1 = _fn(aa, filt)(x, list(size))
+                v1 = _lib.last_variant()
+                _lib.set_fused(0)
+                y0 = _fn(aa, filt)(x, list(size))
+            finally:
+                _lib.set_fused(1)
+            assert v1 == ("fused_u8_planar_pil_v3" if planar else "fused_u8_nhwc_pil_v3"), (v1, filt, size, planar)
+            assert torch.equal(y1, y0), (filt, size, planar)
+            assert np.array_equal(y1.cpu().numpy(), oracle.pil_resize_u8(filt, x.cpu().numpy(), size)), (filt, size, planar)
+    # beyond 136 taps: the generic path
+    y = aa.cubic_forward(x_hwc.permute(0, 3, 1, 2), [40, 12])
     assert _lib.last_variant().startswith("generic"), _lib.last_variant()
-    assert np.array_equal(y.cpu().numpy(), oracle.pil_resize_u8("cubic", x_hwc.permute(0, 3, 1, 2).cpu().numpy(), (40, 40)))
+    assert np.array_equal(y.cpu().numpy(), oracle.pil_resize_u8("cubic", x_hwc.permute(0, 3, 1, 2).cpu().numpy(), (40, 12)))
 
 
 def test_strided_views_are_read_in_place(aa, monkeypatch):
