@@ -564,7 +564,7 @@ int quads_for(int taps, int epq) {
     return 0;
   }
   if (epq == 4) {
-    const int opts[] = {2, 3, 4, 5, 7, 9};  // (9: 33 taps — test.py's bicubic 906 -> 120 thumbnails)
+    const int opts[] = {2, 3, 4, 5, 7, 9, 11};  // (9: 33 taps — test.py's bicubic 906 -> 120 thumbnails; 11: 41 — 4K -> 224 bilinear)
     for (int o : opts)
       if (taps <= 4 * o - 3) return o;
     return 0;
@@ -619,6 +619,13 @@ bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw
     g->strip_w = 32;
     g->nstrips = (int)((oW + 31) / 32);
     g->nseg = (span32 + (epq - 1) + epq * g->nq + (pe - 1)) / pe;
+    if (g->nseg > 128) {  // stronger still (1920 -> 128: 15 x): strips of 16 columns — the input stream is what such a shape costs
+      const int by4s = 5 * (aw.span4p1 - 1) + 1;
+      const int span16 = by4s < aw.span64p1 ? by4s : aw.span64p1;
+      g->strip_w = 16;
+      g->nstrips = (int)((oW + 15) / 16);
+      g->nseg = (span16 + (epq - 1) + epq * g->nq + (pe - 1)) / pe;
+    }
   }
   return g->nseg <= 128;
 }
@@ -699,7 +706,8 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
       case 4: rc = launch_q<4, AA_F32>(mc, p, q); break;
       case 5: rc = launch_q<5, AA_F32>(mc, p, q); break;
       case 7: rc = launch_q<7, AA_F32>(mc, p, q); break;
-      default: rc = launch_q<9, AA_F32>(mc, p, q); break;
+      case 9: rc = launch_q<9, AA_F32>(mc, p, q); break;
+      default: rc = launch_q<11, AA_F32>(mc, p, q); break;
 #endif
     }
 #if !AA_F32_FAST
@@ -719,7 +727,8 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
       case 4: rc = launch_q<4, AA_F16>(mc, p, q); break;
       case 5: rc = launch_q<5, AA_F16>(mc, p, q); break;
       case 7: rc = launch_q<7, AA_F16>(mc, p, q); break;
-      default: rc = launch_q<9, AA_F16>(mc, p, q); break;
+      case 9: rc = launch_q<9, AA_F16>(mc, p, q); break;
+      default: rc = launch_q<11, AA_F16>(mc, p, q); break;
     }
   } else {
     switch (g.nq) {
@@ -728,7 +737,8 @@ int aa_try_fused_float_nchw(const AAProblem &q, const char **variant) {
       case 4: rc = launch_q<4, AA_BF16>(mc, p, q); break;
       case 5: rc = launch_q<5, AA_BF16>(mc, p, q); break;
       case 7: rc = launch_q<7, AA_BF16>(mc, p, q); break;
-      default: rc = launch_q<9, AA_BF16>(mc, p, q); break;
+      case 9: rc = launch_q<9, AA_BF16>(mc, p, q); break;
+      default: rc = launch_q<11, AA_BF16>(mc, p, q); break;
     }
   }
 #if AA_F32_FAST

@@ -1554,7 +1554,7 @@ def test_wide_windows_take_the_fused_uint8_kernel(aa, golden_kat):
                         assert np.array_equal(y1.cpu().numpy(), oracle.harness_u8(filt, x.cpu().numpy(), size)), (filt, size, planar)
     # fp32 planes: 33-tap windows (9 aligned reads per row, lane masks in vector registers) on strips of 32 columns
     xf = x_hwc.permute(0, 3, 1, 2).float().contiguous()
-    for filt, size in (("cubic", (96, 120)), ("cubic", (200, 130)), ("linear", (60, 110))):
+    for filt, size in (("cubic", (96, 120)), ("cubic", (200, 130)), ("linear", (60, 110)), ("linear", (60, 52)), ("cubic", (90, 100))):  # (the last two: 35-41 taps, 11 reads, strips of 16 / 32 columns)
         y = _fn(aa, filt)(xf, list(size))
         assert _lib.last_variant() == "fused_f32_nchw", (_lib.last_variant(), filt, size)
         assert np.array_equal(y.cpu().numpy(), oracle.forward(filt, xf.cpu().numpy(), size, nthreads=8)), (filt, size)
