@@ -602,6 +602,14 @@ bool f32_geometry(int dtype, int layout, int64_t C, int64_t W, const aa_axis &aw
       g->strip_w = 32;
       g->nstrips = (int)((oWe + 31) / 32);
       g->nseg = ((spread32 + 4 * g->nq) * (int)C + 3 + (int)C + 3) / 4 + 1;
+      if (g->nseg > 128) {  // stronger still (3840 -> 224): strips of 16 elements
+        const int steps16 = (15 / (int)C + 1 + 2) / 3;
+        int spread16 = steps16 * (aw.span4p1 - 1);
+        if (spread16 > aw.span64p1 - 1) spread16 = aw.span64p1 - 1;
+        g->strip_w = 16;
+        g->nstrips = (int)((oWe + 15) / 16);
+        g->nseg = ((spread16 + 4 * g->nq) * (int)C + 3 + (int)C + 3) / 4 + 1;
+      }
     }
     return g->nseg <= 128;
   }
