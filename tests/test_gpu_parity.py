@@ -1251,8 +1251,10 @@ def test_fuzz_strong_downscales(aa):
 def test_fuzz_vs_oracle_small(aa):
     """80 seeded random small problems straight against the oracle (bit-exact): fp32 / fp64 forward in both layouts, uint8 in Pillow
     and harness arithmetic, including sizes of 1, up-scales and windows clipped at both borders."""
-    rng = np.random.default_rng(77)
-    for it in range(80):
+    import os
+
+    rng = np.random.default_rng(int(os.environ.get("AA_FUZZ_ORACLE_SEED", "77")))   # (a soak: AA_FUZZ_ORACLE_CASES=3000 AA_FUZZ_ORACLE_SEED=<n>)
+    for it in range(int(os.environ.get("AA_FUZZ_ORACLE_CASES", "80"))):
         c = int(rng.choice([1, 3, 4]))
         n = int(rng.integers(1, 3))
         h, w = int(rng.integers(1, 90)), int(rng.integers(1, 90))
