@@ -240,7 +240,17 @@ def secondary_configs(dev, with_atomics=False):
     x = x.contiguous()
     add("uint8 NCHW (planar) [1024,3,906,438]->[320,196] bilinear", lambda: aa.linear_forward(x, [320, 196]),
         1024 * 3 * (906 * 438 + 320 * 196))
+    add("test.py's own uint8 path: CHW bytes [1024,3,906,438] in the harness's float arithmetic (float(), fp32 op, byte())",
+        lambda: aa.linear_forward(x, [320, 196], uint8_mode="harness"), 1024 * 3 * (906 * 438 + 320 * 196))
     del x
+    x = torch.randint(0, 256, (32, 2160, 3840, 3), dtype=torch.uint8, device=dev).permute(0, 3, 1, 2)
+    add("thumbnails: uint8 channels_last [32,3,2160,3840]->[224,224] bicubic (69 taps: four lanes per pixel, DPP reduction; Pillow-exact)",
+        lambda: aa.cubic_forward(x, [224, 224]), 32 * 3 * (2160 * 3840 + 224 * 224))
+    del x
+    xh = (torch.rand(64, 3, 438, 906, device=dev) * 255).half()
+    add("fp16 NCHW up-scaling [64,3,438,906]->[1200,1200] bilinear, bit-exact half(reference_fp32)", lambda: aa.linear_forward(xh, [1200, 1200]),
+        64 * 3 * 2 * (438 * 906 + 1200 * 1200))
+    del xh
     g = torch.randn(256, 3, 196, 320, device=dev)
     add("configs[4] batched: backward fp32 grad [256,3,196,320]->[256,3,438,906], gather form (true adjoint)",
         lambda: aa.linear_backward(g, [196, 320], [256, 3, 438, 906]), 256 * 3 * 4 * (438 * 906 + 196 * 320))
