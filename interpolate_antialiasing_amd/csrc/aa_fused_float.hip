@@ -532,7 +532,11 @@ int launch_m(int maxc, const FusedF32Params &p, const AAProblem &q) {
 // staged rows per wave: 8 while a row segment is one DMA instruction (<= 1 KiB), 4 beyond (rings stay <= 8 KiB per wave)
 template <int NQ, int DT, int CS = 1>
 int launch_q(int maxc, const FusedF32Params &p, const AAProblem &q) {
-  return p.nseg <= 64 ? launch_m<NQ, 8, 1, DT, CS>(maxc, p, q) : launch_m<NQ, 4, 2, DT, CS>(maxc, p, q);
+#ifndef AA_F32_G_WIDE
+#define AA_F32_G_WIDE 4  // staged rows of segments beyond one DMA.  8 measured the same within noise on config 2 (exact 0.192 | 0.193 ms, tolerance mode
+                         // 0.162-0.176 | 0.166-0.180): the deeper ring buys nothing
+#endif
+  return p.nseg <= 64 ? launch_m<NQ, 8, 1, DT, CS>(maxc, p, q) : launch_m<NQ, AA_F32_G_WIDE, 2, DT, CS>(maxc, p, q);
 }
 
 template <int CS>
