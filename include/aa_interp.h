@@ -150,6 +150,9 @@ int aa_table_transpose(const void *table_dev, void *tr_table_dev, size_t tr_tabl
 /* Copy a table header back to the host.  SYNCHRONISES `stream` (one-off, at table-build time, never in the
  * per-call path). */
 int aa_table_query(const void *table_dev, aa_table_header *host_header, aa_stream_t stream);
+/* The same for the two tables of a call (H and W axis) with ONE synchronisation: a shape never seen before costs two table builds, and a
+ * data pipeline of random crops meets a new shape on every call. */
+int aa_table_query2(const void *table_a_dev, const void *table_b_dev, aa_table_header *host_a, aa_table_header *host_b, aa_stream_t stream);
 
 /* Workspace (bytes) the forward needs for this problem; 0 when a fused single-launch path applies.  The answer depends on the
  * shape and the tables only, never on the pointers: which kernel runs is decided from the same facts, and a uint8 view that starts

@@ -184,6 +184,15 @@ int aa_table_query(const void *table_dev, aa_table_header *host_header, aa_strea
   return AA_OK;
 }
 
+int aa_table_query2(const void *table_a_dev, const void *table_b_dev, aa_table_header *host_a, aa_table_header *host_b, aa_stream_t stream) {
+  if (!table_a_dev || !table_b_dev || !host_a || !host_b) return AA_ERR_NULL;
+  if (hipMemcpyAsync(host_a, table_a_dev, sizeof(aa_table_header), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return AA_ERR_HIP;
+  if (hipMemcpyAsync(host_b, table_b_dev, sizeof(aa_table_header), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return AA_ERR_HIP;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return AA_ERR_HIP;
+  if (host_a->magic != AA_TABLE_MAGIC || host_b->magic != AA_TABLE_MAGIC) return AA_ERR_BAD_SHAPE;
+  return AA_OK;
+}
+
 int aa_table_transpose(const void *table_dev, void *tr_table_dev, size_t tr_table_bytes, int tr_ksize,
                        aa_stream_t stream) {
   if (!table_dev || !tr_table_dev) return AA_ERR_NULL;

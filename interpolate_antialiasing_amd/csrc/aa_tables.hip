@@ -45,9 +45,7 @@ __device__ inline S apply_filter(int filter, S x) {
 __device__ inline int interp_size_of(int filter) { return filter == AA_FILTER_LINEAR ? 2 : (filter == AA_FILTER_CUBIC ? 4 : 1); }
 
 // Reference arithmetic, scalar_t = float (s2.2:207-209, :242, :253-278).  Every promotion spelled out.
-__global__ void table_build_f32(int filter, int in_size, int out_size, int ksize, float scale, char *table) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= out_size) return;
+__device__ void table_build_f32_one(int i, int filter, int in_size, int out_size, int ksize, float scale, char *table) {
   int32_t *xmin_p = (int32_t *)(table + aa_table_xmin_off());
   int32_t *xsize_p = (int32_t *)(table + aa_table_xsize_off(out_size));
   float *w = (float *)(table + aa_table_w_off(out_size)) + (size_t)i * ksize;
@@ -81,11 +79,13 @@ __global__ void table_build_f32(int filter, int in_size, int out_size, int ksize
   for (; j < ksize; j++) w[j] = 0.0f;
   atomicMax(max_taps, (int32_t)(xmax > 1 ? xmax : 1));
 }
+__global__ void table_build_f32(int filter, int in_size, int out_size, int ksize, float scale, char *table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < out_size) table_build_f32_one(i, filter, in_size, out_size, ksize, scale, table);
+}
 
 // scalar_t = double
-__global__ void table_build_f64(int filter, int in_size, int out_size, int ksize, double scale, char *table) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= out_size) return;
+__device__ void table_build_f64_one(int i, int filter, int in_size, int out_size, int ksize, double scale, char *table) {
   int32_t *xmin_p = (int32_t *)(table + aa_table_xmin_off());
   int32_t *xsize_p = (int32_t *)(table + aa_table_xsize_off(out_size));
   double *w = (double *)(table + aa_table_w_off(out_size)) + (size_t)i * ksize;
@@ -115,12 +115,14 @@ __global__ void table_build_f64(int filter, int in_size, int out_size, int ksize
   for (; j < ksize; j++) w[j] = 0.0;
   atomicMax(max_taps, (int32_t)(xmax > 1 ? xmax : 1));
 }
+__global__ void table_build_f64(int filter, int in_size, int out_size, int ksize, double scale, char *table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < out_size) table_build_f64_one(i, filter, in_size, out_size, ksize, scale, table);
+}
 
 // Pillow: precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c, cited by URL in the reference:
 // README.md:18,40; s2.2/aa_interpolation_impl.h:289-291).  double coefficients -> 22-bit fixed point int32.
-__global__ void table_build_pil(int filter, int in_size, int out_size, int ksize, char *table) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= out_size) return;
+__device__ void table_build_pil_one(int i, int filter, int in_size, int out_size, int ksize, char *table) {
   int32_t *xmin_p = (int32_t *)(table + aa_table_xmin_off());
   int32_t *xsize_p = (int32_t *)(table + aa_table_xsize_off(out_size));
   int32_t *kk = (int32_t *)(table + aa_table_w_off(out_size)) + (size_t)i * ksize;
@@ -151,13 +153,15 @@ __global__ void table_build_pil(int filter, int in_size, int out_size, int ksize
   for (; x < ksize; x++) kk[x] = 0;
   atomicMax(max_taps, (int32_t)(xmax > 1 ? xmax : 1));
 }
+__global__ void table_build_pil(int filter, int in_size, int out_size, int ksize, char *table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < out_size) table_build_pil_one(i, filter, in_size, out_size, ksize, table);
+}
 
 // header.span64p1 = 1 + max_i (xmin[min(i+63, out-1)] - xmin[i]): the fused kernels stage, per strip of <= 64 consecutive
 // outputs, the input range their windows cover; they size that range from this MEASURED spread (an explicit scale
 // factor or align_corners moves the windows apart differently from in/out).  Runs after the table's own kernel.
-__global__ void table_span_kernel(char *table, int out_size) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= out_size) return;
+__device__ void table_span_one(int i, char *table, int out_size) {
   const int32_t *xmin = (const int32_t *)(table + aa_table_xmin_off());
   const int j = i + 63 < out_size ? i + 63 : out_size - 1;
   int d = xmin[j] - xmin[i];
@@ -168,11 +172,13 @@ __global__ void table_span_kernel(char *table, int out_size) {
   if (d4 < 0) d4 = 0;
   atomicMax(&((aa_table_header *)table)->span4p1, d4 + 1);
 }
+__global__ void table_span_kernel(char *table, int out_size) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < out_size) table_span_one(i, table, out_size);
+}
 
 // gather section: record i = {xmin[i], xsize[i], w[i][0..5]} (weights beyond ksize are 0): one scalar load per output row
-__global__ void table_gather_kernel(char *table, int out_size, int ksize, int gather_off) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= out_size) return;
+__device__ void table_gather_one(int i, char *table, int out_size, int ksize, int gather_off) {
   const int32_t *xmin = (const int32_t *)(table + aa_table_xmin_off());
   const int32_t *xsize = (const int32_t *)(table + aa_table_xsize_off(out_size));
   const int32_t *w = (const int32_t *)(table + aa_table_w_off(out_size)) + (size_t)i * ksize;  // float bits
@@ -180,6 +186,10 @@ __global__ void table_gather_kernel(char *table, int out_size, int ksize, int ga
   rec[0] = xmin[i];
   rec[1] = xsize[i];
   for (int k = 0; k < 6; k++) rec[2 + k] = k < ksize ? w[k] : 0;
+}
+__global__ void table_gather_kernel(char *table, int out_size, int ksize, int gather_off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < out_size) table_gather_one(i, table, out_size, ksize, gather_off);
 }
 
 __global__ void table_write_header(aa_table_header h, char *table) {
@@ -231,10 +241,7 @@ __global__ void table_transpose_kernel(const char *fwd, int32_t *tmin, int32_t *
 // Scatter section of AA_TABLE_PIL tables: one 32-byte record per INPUT index x, read by the fused kernels with a
 // single s_load_dwordx8: {first output fed, number of outputs fed, weight in output first+0 .. first+5}.
 template <typename WT>
-__global__ void table_scatter_kernel(const char *fwd, int32_t *rec_all, int32_t *scatter_max, int in_size, int out_size,
-                                     int ksize) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x > in_size) return;  // record in_size is a sentinel (feeds nothing, completes nothing): readers may prefetch it
+__device__ void table_scatter_one(int x, const char *fwd, int32_t *rec_all, int32_t *scatter_max, int in_size, int out_size, int ksize) {
   const int32_t *xmin = (const int32_t *)(fwd + aa_table_xmin_off());
   const int32_t *xsize = (const int32_t *)(fwd + aa_table_xsize_off(out_size));
   const WT *w = (const WT *)(fwd + aa_table_w_off(out_size));  // (int32 and float weights travel bit for bit; doubles as doubles)
@@ -266,6 +273,42 @@ __global__ void table_scatter_kernel(const char *fwd, int32_t *rec_all, int32_t 
   }
   atomicMax(scatter_max, cnt > 1 ? cnt : 1);
 }
+template <typename WT>
+__global__ void table_scatter_kernel(const char *fwd, int32_t *rec_all, int32_t *scatter_max, int in_size, int out_size,
+                                     int ksize) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x <= in_size) table_scatter_one<WT>(x, fwd, rec_all, scatter_max, in_size, out_size, ksize);  // (record in_size is a sentinel: feeds nothing,
+                                                                                                    //  completes nothing; readers may prefetch it)
+}
+
+// One launch for a whole table (round 3): header, rows, scatter records, measured spreads, gather records — the phases of the five launches
+// above, run by ONE workgroup with a barrier between them.  A table is a few thousand entries of a few dozen operations: the five launches
+// cost five launch latencies (a cold call = a shape never seen: two tables = ~0.1 ms of them; a data pipeline of random crops meets a
+// new shape every call).  Same device functions, same results.
+template <int KIND>
+__global__ void __launch_bounds__(1024) table_build_all(aa_table_header h, int filter, int in_size, int out_size, int ksize, double scale, char *table) {
+  if (threadIdx.x == 0) *(aa_table_header *)table = h;
+  __syncthreads();
+  for (int i = threadIdx.x; i < out_size; i += blockDim.x) {
+    if constexpr (KIND == AA_TABLE_F32) table_build_f32_one(i, filter, in_size, out_size, ksize, (float)scale, table);
+    else if constexpr (KIND == AA_TABLE_F64) table_build_f64_one(i, filter, in_size, out_size, ksize, scale, table);
+    else table_build_pil_one(i, filter, in_size, out_size, ksize, table);
+  }
+  __threadfence();
+  __syncthreads();
+  if (h.scatter_off) {
+    int32_t *rec_all = (int32_t *)(table + h.scatter_off);
+    int32_t *smax = &((aa_table_header *)table)->scatter_max;
+    for (int x = threadIdx.x; x <= in_size; x += blockDim.x) {
+      if constexpr (KIND == AA_TABLE_F64) table_scatter_one<double>(x, table, rec_all, smax, in_size, out_size, ksize);
+      else table_scatter_one<int32_t>(x, table, rec_all, smax, in_size, out_size, ksize);
+    }
+  }
+  for (int i = threadIdx.x; i < out_size; i += blockDim.x) {
+    table_span_one(i, table, out_size);
+    if (h.gather_off) table_gather_one(i, table, out_size, ksize, h.gather_off);
+  }
+}
 
 }  // namespace
 
@@ -292,6 +335,16 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
     h.scatter_ksize = scatter_ksize;
   }
   char *t = (char *)table_dev;
+  if (out_size <= 16384 && in_size <= 32768) {  // one launch, one workgroup (see table_build_all); larger tables: the five launches below
+    if (kind == AA_TABLE_F32)
+      hipLaunchKernelGGL(table_build_all<AA_TABLE_F32>, dim3(1), dim3(1024), 0, stream, h, filter, (int)in_size, (int)out_size, ksize, scale, t);
+    else if (kind == AA_TABLE_F64)
+      hipLaunchKernelGGL(table_build_all<AA_TABLE_F64>, dim3(1), dim3(1024), 0, stream, h, filter, (int)in_size, (int)out_size, ksize, scale, t);
+    else
+      hipLaunchKernelGGL(table_build_all<AA_TABLE_PIL>, dim3(1), dim3(1024), 0, stream, h, filter, (int)in_size, (int)out_size, ksize, scale, t);
+    AA_HIP_CHECK_LAUNCH();
+    return AA_OK;
+  }
   hipLaunchKernelGGL(table_write_header, dim3(1), dim3(64), 0, stream, h, t);
   const int threads = 128;
   const int blocks = (int)((out_size + threads - 1) / threads);

@@ -178,8 +178,7 @@ def _forward(filter_id: int, name: str, input: torch.Tensor, output_size: Sequen
     cur = torch.cuda.current_device()
     if plan is None:
         with torch.cuda.device(dev):
-            th = tables.get_table(filter_id, kind, h, oh, align_corners, sh, dev)
-            tw = tables.get_table(filter_id, kind, w, ow, align_corners, sw, dev)
+            th, tw = tables.get_table_pair(filter_id, kind, h, oh, w, ow, align_corners, sh, sw, dev)
             ah, aw = th.axis(), tw.axis()
             ws_bytes = L.aa_workspace_bytes(dt, layout, n, c, h, w, oh, ow, ctypes.byref(ah), ctypes.byref(aw))
         plan = (ah, aw, ws_bytes, ctypes.byref(ah), ctypes.byref(aw), th, tw)  # (th, tw keep the device buffers alive)
@@ -246,8 +245,7 @@ def _forward_to_float(filter_id: int, name: str, input: torch.Tensor, output_siz
     if n == 0:
         return out
     with torch.cuda.device(dev):
-        th = tables.get_table(filter_id, _lib.TABLE_F32, h, oh, align_corners, sh, dev)
-        tw = tables.get_table(filter_id, _lib.TABLE_F32, w, ow, align_corners, sw, dev)
+        th, tw = tables.get_table_pair(filter_id, _lib.TABLE_F32, h, oh, w, ow, align_corners, sh, sw, dev)
         ah, aw = th.axis(), tw.axis()
         ws_bytes = L.aa_workspace_bytes_u8_to_f32(layout, n, c, h, w, ctypes.byref(ah), ctypes.byref(aw), ctypes.byref(cv))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None

@@ -142,6 +142,52 @@ def build_table(filter_id: int, kind: int, in_size: int, out_size: int, align_co
                        int(hdr.scatter_off), int(hdr.scatter_ksize), int(hdr.scatter_max), int(hdr.span64p1), int(hdr.span4p1), int(hdr.gather_off))
 
 
+def _launch_build(filter_id: int, kind: int, in_size: int, out_size: int, align_corners: bool, scale: float, device: torch.device):
+    """The asynchronous half of build_table: -> (buffer, ksize).  The header still has to be read back (aa_table_query)."""
+    L = _lib.load()
+    k = L.aa_table_ksize(filter_id, kind, in_size, out_size, int(align_corners), float(scale or 0.0))
+    _lib.check(k, "aa_table_ksize")
+    nbytes = L.aa_table_build_bytes(filter_id, kind, in_size, out_size, int(align_corners), float(scale or 0.0))
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _lib.check(L.aa_table_build(filter_id, kind, in_size, out_size, int(align_corners), float(scale or 0.0),
+                                ctypes.c_void_p(buf.data_ptr()), nbytes, _stream_ptr(device)), "aa_table_build")
+    return buf, k
+
+
+def _from_header(buf, filter_id, kind, in_size, out_size, k, align_corners, hdr) -> WeightTable:
+    return WeightTable(buf, filter_id, kind, in_size, out_size, k, int(hdr.max_taps), bool(align_corners), False,
+                       int(hdr.scatter_off), int(hdr.scatter_ksize), int(hdr.scatter_max), int(hdr.span64p1), int(hdr.span4p1), int(hdr.gather_off))
+
+
+def get_table_pair(filter_id: int, kind: int, in_h: int, out_h: int, in_w: int, out_w: int, align_corners: bool, scale_h: float, scale_w: float,
+                   device: torch.device):
+    """The two tables of a 2-D call.  When BOTH are new (a shape never seen: every call of a random-crop pipeline) they are built
+    back to back and their headers read with one synchronisation instead of two."""
+    device = torch.device(device)
+    kh = cache_key(filter_id, kind, in_h, out_h, align_corners, scale_h, device)
+    kw = cache_key(filter_id, kind, in_w, out_w, align_corners, scale_w, device)
+    with _cache_lock:
+        th, tw = _cache.get(kh), _cache.get(kw)
+    if th is None and tw is None and kh != kw:
+        L = _lib.load()
+        with torch.cuda.device(device):
+            bh, k_h = _launch_build(filter_id, kind, in_h, out_h, align_corners, scale_h, device)
+            bw, k_w = _launch_build(filter_id, kind, in_w, out_w, align_corners, scale_w, device)
+            hh, hw = _lib.TableHeader(), _lib.TableHeader()
+            _lib.check(L.aa_table_query2(ctypes.c_void_p(bh.data_ptr()), ctypes.c_void_p(bw.data_ptr()), ctypes.byref(hh), ctypes.byref(hw),
+                                         _stream_ptr(device)), "aa_table_query2")
+        th = _from_header(bh, filter_id, kind, in_h, out_h, k_h, align_corners, hh)
+        tw = _from_header(bw, filter_id, kind, in_w, out_w, k_w, align_corners, hw)
+        with _cache_lock:
+            _cache[kh], _cache[kw] = th, tw
+        return th, tw
+    if th is None:
+        th = get_table(filter_id, kind, in_h, out_h, align_corners, scale_h, device)
+    if tw is None:
+        tw = get_table(filter_id, kind, in_w, out_w, align_corners, scale_w, device)
+    return th, tw
+
+
 def get_table(filter_id: int, kind: int, in_size: int, out_size: int, align_corners: bool = False, scale: float = 0.0,
               device: Optional[torch.device] = None) -> WeightTable:
     device = torch.device(device if device is not None else "cuda")
