@@ -150,7 +150,10 @@ int aa_table_transpose(const void *table_dev, void *tr_table_dev, size_t tr_tabl
 /* Copy a table header back to the host.  SYNCHRONISES `stream` (one-off, at table-build time, never in the
  * per-call path). */
 int aa_table_query(const void *table_dev, aa_table_header *host_header, aa_stream_t stream);
-/* The same for the two tables of a call (H and W axis) with ONE synchronisation: a shape never seen before costs two table builds, and a
+/* aa_table_build for the two tables of a call (H and W axis: same filter, kind and align_corners) as ONE launch. */
+int aa_table_build2(int filter, int kind, int align_corners, int64_t in_a, int64_t out_a, double scale_a, void *table_a_dev, size_t bytes_a,
+                    int64_t in_b, int64_t out_b, double scale_b, void *table_b_dev, size_t bytes_b, aa_stream_t stream);
+/* aa_table_query for the two tables of a call (H and W axis) with ONE synchronisation: a shape never seen before costs two table builds, and a
  * data pipeline of random crops meets a new shape on every call. */
 int aa_table_query2(const void *table_a_dev, const void *table_b_dev, aa_table_header *host_a, aa_table_header *host_b, aa_stream_t stream);
 

@@ -27,7 +27,7 @@ FLAG_FAST = 1
 # every symbol include/aa_interp.h declares (tests check the .so exports exactly these)
 EXPORTS = (
     "aa_abi_version", "aa_strerror", "aa_device_count", "aa_table_ksize", "aa_table_bytes", "aa_table_build_bytes", "aa_table_build",
-    "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_table_query2", "aa_workspace_bytes", "aa_resample_fwd",
+    "aa_table_transposed_ksize", "aa_table_transpose", "aa_table_query", "aa_table_query2", "aa_table_build2", "aa_workspace_bytes", "aa_resample_fwd",
     "aa_resample_bwd", "aa_resample_bwd_atomic", "aa_workspace_bytes_bwd", "aa_resample_axis_fwd", "aa_set_fused",
     "aa_last_variant", "aa_probe_copy", "aa_workspace_bytes_u8_to_f32", "aa_resample_fwd_u8_to_f32", "aa_set_store_form", "aa_set_plane_groups", "aa_resample_fwd_ex", "aa_resample_fwd_strided",
 )
@@ -97,6 +97,8 @@ def load() -> ctypes.CDLL:
     L.aa_table_query.restype = i32
     L.aa_table_query2.argtypes = [vp, vp, ctypes.POINTER(TableHeader), ctypes.POINTER(TableHeader), vp]
     L.aa_table_query2.restype = i32
+    L.aa_table_build2.argtypes = [i32, i32, i32, i64, i64, ctypes.c_double, vp, sz, i64, i64, ctypes.c_double, vp, sz, vp]
+    L.aa_table_build2.restype = i32
     L.aa_workspace_bytes.argtypes = [i32, i32, i64, i64, i64, i64, i64, i64, ax, ax]
     L.aa_workspace_bytes.restype = sz
     L.aa_resample_fwd.argtypes = [vp, vp, vp, sz, i32, i32, i64, i64, i64, i64, ax, ax, vp]

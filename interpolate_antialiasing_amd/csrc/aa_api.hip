@@ -157,6 +157,27 @@ int aa_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int 
                                (hipStream_t)stream);
 }
 
+int aa_table_build2(int filter, int kind, int align_corners, int64_t in_a, int64_t out_a, double scale_a, void *table_a_dev, size_t bytes_a,
+                    int64_t in_b, int64_t out_b, double scale_b, void *table_b_dev, size_t bytes_b, aa_stream_t stream) {
+  const int ka = aa_table_ksize(filter, kind, in_a, out_a, align_corners, scale_a);
+  if (ka < 0) return ka;
+  const int kb = aa_table_ksize(filter, kind, in_b, out_b, align_corners, scale_b);
+  if (kb < 0) return kb;
+  if (!table_a_dev || !table_b_dev) return AA_ERR_NULL;
+  const int ska = scatter_ksize_for(filter, kind, in_a, out_a), skb = scatter_ksize_for(filter, kind, in_b, out_b);
+  if (bytes_a < aa_table_total_bytes(kind, out_a, ka) + aa_table_scatter_bytes(kind, in_a, ska)) return AA_ERR_WORKSPACE;
+  if (bytes_b < aa_table_total_bytes(kind, out_b, kb) + aa_table_scatter_bytes(kind, in_b, skb)) return AA_ERR_WORKSPACE;
+  if (!aa_table_pair_fits(in_a, out_a, in_b, out_b)) {  // very large tables: one after the other
+    const int rc = aa_launch_table_build(filter, kind, in_a, out_a, align_corners, scale_for(kind, in_a, out_a, align_corners, scale_a), ka, ska, table_a_dev,
+                                         (hipStream_t)stream);
+    if (rc != AA_OK) return rc;
+    return aa_launch_table_build(filter, kind, in_b, out_b, align_corners, scale_for(kind, in_b, out_b, align_corners, scale_b), kb, skb, table_b_dev,
+                                 (hipStream_t)stream);
+  }
+  return aa_launch_table_build_pair(filter, kind, align_corners, in_a, out_a, scale_for(kind, in_a, out_a, align_corners, scale_a), ka, ska, table_a_dev, in_b,
+                                    out_b, scale_for(kind, in_b, out_b, align_corners, scale_b), kb, skb, table_b_dev, (hipStream_t)stream);
+}
+
 int aa_table_transposed_ksize(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale) {
   const int k = aa_table_ksize(filter, kind, in_size, out_size, align_corners, scale);
   if (k < 0) return k;
@@ -175,20 +196,47 @@ int aa_table_transposed_ksize(int filter, int kind, int64_t in_size, int64_t out
   return tk;
 }
 
+// Header read-backs land in PINNED host memory (one small buffer per process, behind a mutex) and are copied out from there: an
+// asynchronous device-to-host copy into pageable memory — the caller's struct — goes through the runtime's staging path and costs tens of
+// microseconds more per copy (a cold call is two of them).
+namespace {
+std::mutex g_pin_mu;
+aa_table_header *g_pin = nullptr;  // two headers
+aa_table_header *pinned_headers() {  // (call with g_pin_mu held; nullptr: fall back to the caller's memory)
+  if (!g_pin) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, 2 * sizeof(aa_table_header), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    g_pin = (aa_table_header *)p;
+  }
+  return g_pin;
+}
+}  // namespace
+
 int aa_table_query(const void *table_dev, aa_table_header *host_header, aa_stream_t stream) {
   if (!table_dev || !host_header) return AA_ERR_NULL;
-  if (hipMemcpyAsync(host_header, table_dev, sizeof(aa_table_header), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+  std::lock_guard<std::mutex> lock(g_pin_mu);
+  aa_table_header *pin = pinned_headers();
+  aa_table_header *dst = pin ? pin : host_header;
+  if (hipMemcpyAsync(dst, table_dev, sizeof(aa_table_header), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
     return AA_ERR_HIP;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return AA_ERR_HIP;
+  if (pin) *host_header = *pin;
   if (host_header->magic != AA_TABLE_MAGIC) return AA_ERR_BAD_SHAPE;
   return AA_OK;
 }
 
 int aa_table_query2(const void *table_a_dev, const void *table_b_dev, aa_table_header *host_a, aa_table_header *host_b, aa_stream_t stream) {
   if (!table_a_dev || !table_b_dev || !host_a || !host_b) return AA_ERR_NULL;
-  if (hipMemcpyAsync(host_a, table_a_dev, sizeof(aa_table_header), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return AA_ERR_HIP;
-  if (hipMemcpyAsync(host_b, table_b_dev, sizeof(aa_table_header), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return AA_ERR_HIP;
+  std::lock_guard<std::mutex> lock(g_pin_mu);
+  aa_table_header *pin = pinned_headers();
+  aa_table_header *da = pin ? pin : host_a, *db = pin ? pin + 1 : host_b;
+  if (hipMemcpyAsync(da, table_a_dev, sizeof(aa_table_header), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return AA_ERR_HIP;
+  if (hipMemcpyAsync(db, table_b_dev, sizeof(aa_table_header), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return AA_ERR_HIP;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return AA_ERR_HIP;
+  if (pin) { *host_a = pin[0]; *host_b = pin[1]; }
   if (host_a->magic != AA_TABLE_MAGIC || host_b->magic != AA_TABLE_MAGIC) return AA_ERR_BAD_SHAPE;
   return AA_OK;
 }

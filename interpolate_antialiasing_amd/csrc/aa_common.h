@@ -69,6 +69,9 @@ extern int g_aa_plane_groups;
   } while (0)
 
 // entry points implemented in the .hip files and called from aa_api.cpp
+bool aa_table_pair_fits(int64_t in_a, int64_t out_a, int64_t in_b, int64_t out_b);
+int aa_launch_table_build_pair(int filter, int kind, int align_corners, int64_t in_a, int64_t out_a, double scale_a, int ksize_a, int sk_a, void *tab_a,
+                               int64_t in_b, int64_t out_b, double scale_b, int ksize_b, int sk_b, void *tab_b, hipStream_t stream);
 int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
                           int ksize, int scatter_ksize, void *table_dev, hipStream_t stream);
 // bytes of the scatter section appended to AA_TABLE_PIL tables (0 when scatter_ksize == 0)

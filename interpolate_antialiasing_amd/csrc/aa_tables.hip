@@ -241,9 +241,11 @@ __global__ void table_transpose_kernel(const char *fwd, int32_t *tmin, int32_t *
 // Scatter section of AA_TABLE_PIL tables: one 32-byte record per INPUT index x, read by the fused kernels with a
 // single s_load_dwordx8: {first output fed, number of outputs fed, weight in output first+0 .. first+5}.
 template <typename WT>
-__device__ void table_scatter_one(int x, const char *fwd, int32_t *rec_all, int32_t *scatter_max, int in_size, int out_size, int ksize) {
-  const int32_t *xmin = (const int32_t *)(fwd + aa_table_xmin_off());
-  const int32_t *xsize = (const int32_t *)(fwd + aa_table_xsize_off(out_size));
+__device__ void table_scatter_one(int x, const char *fwd, int32_t *rec_all, int32_t *scatter_max, int in_size, int out_size, int ksize,
+                                  const int32_t *xmin_fast = nullptr, const int32_t *xsize_fast = nullptr) {
+  // (xmin_fast / xsize_fast: copies of the two arrays in LDS — the binary searches below are chains of ~30 dependent loads)
+  const int32_t *xmin = xmin_fast ? xmin_fast : (const int32_t *)(fwd + aa_table_xmin_off());
+  const int32_t *xsize = xsize_fast ? xsize_fast : (const int32_t *)(fwd + aa_table_xsize_off(out_size));
   const WT *w = (const WT *)(fwd + aa_table_w_off(out_size));  // (int32 and float weights travel bit for bit; doubles as doubles)
   constexpr int REC_INTS = sizeof(WT) == 8 ? 16 : 8;
   int32_t *rec = rec_all + (size_t)x * REC_INTS;
@@ -285,8 +287,21 @@ __global__ void table_scatter_kernel(const char *fwd, int32_t *rec_all, int32_t 
 // above, run by ONE workgroup with a barrier between them.  A table is a few thousand entries of a few dozen operations: the five launches
 // cost five launch latencies (a cold call = a shape never seen: two tables = ~0.1 ms of them; a data pipeline of random crops meets a
 // new shape every call).  Same device functions, same results.
+struct TableJob { aa_table_header h; int in_size, out_size, ksize; double scale; char *table; };
+template <int KIND>
+__device__ void table_build_body(const aa_table_header &h, int filter, int in_size, int out_size, int ksize, double scale, char *table);
 template <int KIND>
 __global__ void __launch_bounds__(1024) table_build_all(aa_table_header h, int filter, int in_size, int out_size, int ksize, double scale, char *table) {
+  table_build_body<KIND>(h, filter, in_size, out_size, ksize, scale, table);
+}
+// ... and the two tables of a call (H and W axis) as the two workgroups of one launch
+template <int KIND>
+__global__ void __launch_bounds__(1024) table_build_pair(TableJob a, TableJob b, int filter) {
+  const TableJob &j = blockIdx.x == 0 ? a : b;
+  table_build_body<KIND>(j.h, filter, j.in_size, j.out_size, j.ksize, j.scale, j.table);
+}
+template <int KIND>
+__device__ void table_build_body(const aa_table_header &h, int filter, int in_size, int out_size, int ksize, double scale, char *table) {
   if (threadIdx.x == 0) *(aa_table_header *)table = h;
   __syncthreads();
   for (int i = threadIdx.x; i < out_size; i += blockDim.x) {
@@ -296,12 +311,22 @@ __global__ void __launch_bounds__(1024) table_build_all(aa_table_header h, int f
   }
   __threadfence();
   __syncthreads();
+  // window starts and sizes into LDS for the scatter phase's binary searches (dependent loads: ~1 us each from memory, ~0.1 from LDS)
+  constexpr int kFast = 4096;
+  __shared__ int32_t s_xmin[kFast], s_xsize[kFast];
+  const bool fast = out_size <= kFast;
+  if (fast) {
+    const int32_t *gx = (const int32_t *)(table + aa_table_xmin_off());
+    const int32_t *gs = (const int32_t *)(table + aa_table_xsize_off(out_size));
+    for (int i = threadIdx.x; i < out_size; i += blockDim.x) { s_xmin[i] = gx[i]; s_xsize[i] = gs[i]; }
+    __syncthreads();
+  }
   if (h.scatter_off) {
     int32_t *rec_all = (int32_t *)(table + h.scatter_off);
     int32_t *smax = &((aa_table_header *)table)->scatter_max;
     for (int x = threadIdx.x; x <= in_size; x += blockDim.x) {
-      if constexpr (KIND == AA_TABLE_F64) table_scatter_one<double>(x, table, rec_all, smax, in_size, out_size, ksize);
-      else table_scatter_one<int32_t>(x, table, rec_all, smax, in_size, out_size, ksize);
+      if constexpr (KIND == AA_TABLE_F64) table_scatter_one<double>(x, table, rec_all, smax, in_size, out_size, ksize, fast ? s_xmin : nullptr, fast ? s_xsize : nullptr);
+      else table_scatter_one<int32_t>(x, table, rec_all, smax, in_size, out_size, ksize, fast ? s_xmin : nullptr, fast ? s_xsize : nullptr);
     }
   }
   for (int i = threadIdx.x; i < out_size; i += blockDim.x) {
@@ -312,8 +337,24 @@ __global__ void __launch_bounds__(1024) table_build_all(aa_table_header h, int f
 
 }  // namespace
 
-int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
-                          int ksize, int scatter_ksize, void *table_dev, hipStream_t stream) {
+static aa_table_header make_header(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, int ksize, int scatter_ksize);
+
+bool aa_table_pair_fits(int64_t in_a, int64_t out_a, int64_t in_b, int64_t out_b) {
+  return out_a <= 16384 && in_a <= 32768 && out_b <= 16384 && in_b <= 32768;
+}
+
+int aa_launch_table_build_pair(int filter, int kind, int align_corners, int64_t in_a, int64_t out_a, double scale_a, int ksize_a, int sk_a, void *tab_a,
+                               int64_t in_b, int64_t out_b, double scale_b, int ksize_b, int sk_b, void *tab_b, hipStream_t stream) {
+  TableJob a = {make_header(filter, kind, in_a, out_a, align_corners, ksize_a, sk_a), (int)in_a, (int)out_a, ksize_a, scale_a, (char *)tab_a};
+  TableJob b = {make_header(filter, kind, in_b, out_b, align_corners, ksize_b, sk_b), (int)in_b, (int)out_b, ksize_b, scale_b, (char *)tab_b};
+  if (kind == AA_TABLE_F32) hipLaunchKernelGGL(table_build_pair<AA_TABLE_F32>, dim3(2), dim3(1024), 0, stream, a, b, filter);
+  else if (kind == AA_TABLE_F64) hipLaunchKernelGGL(table_build_pair<AA_TABLE_F64>, dim3(2), dim3(1024), 0, stream, a, b, filter);
+  else hipLaunchKernelGGL(table_build_pair<AA_TABLE_PIL>, dim3(2), dim3(1024), 0, stream, a, b, filter);
+  AA_HIP_CHECK_LAUNCH();
+  return AA_OK;
+}
+
+static aa_table_header make_header(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, int ksize, int scatter_ksize) {
   aa_table_header h = {};
   h.magic = AA_TABLE_MAGIC;
   h.filter = filter;
@@ -334,6 +375,12 @@ int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_siz
     h.scatter_off = (int32_t)aa_table_total_bytes(kind, out_size, ksize);
     h.scatter_ksize = scatter_ksize;
   }
+  return h;
+}
+
+int aa_launch_table_build(int filter, int kind, int64_t in_size, int64_t out_size, int align_corners, double scale,
+                          int ksize, int scatter_ksize, void *table_dev, hipStream_t stream) {
+  const aa_table_header h = make_header(filter, kind, in_size, out_size, align_corners, ksize, scatter_ksize);
   char *t = (char *)table_dev;
   if (out_size <= 16384 && in_size <= 32768) {  // one launch, one workgroup (see table_build_all); larger tables: the five launches below
     if (kind == AA_TABLE_F32)

@@ -142,18 +142,6 @@ def build_table(filter_id: int, kind: int, in_size: int, out_size: int, align_co
                        int(hdr.scatter_off), int(hdr.scatter_ksize), int(hdr.scatter_max), int(hdr.span64p1), int(hdr.span4p1), int(hdr.gather_off))
 
 
-def _launch_build(filter_id: int, kind: int, in_size: int, out_size: int, align_corners: bool, scale: float, device: torch.device):
-    """The asynchronous half of build_table: -> (buffer, ksize).  The header still has to be read back (aa_table_query)."""
-    L = _lib.load()
-    k = L.aa_table_ksize(filter_id, kind, in_size, out_size, int(align_corners), float(scale or 0.0))
-    _lib.check(k, "aa_table_ksize")
-    nbytes = L.aa_table_build_bytes(filter_id, kind, in_size, out_size, int(align_corners), float(scale or 0.0))
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    _lib.check(L.aa_table_build(filter_id, kind, in_size, out_size, int(align_corners), float(scale or 0.0),
-                                ctypes.c_void_p(buf.data_ptr()), nbytes, _stream_ptr(device)), "aa_table_build")
-    return buf, k
-
-
 def _from_header(buf, filter_id, kind, in_size, out_size, k, align_corners, hdr) -> WeightTable:
     return WeightTable(buf, filter_id, kind, in_size, out_size, k, int(hdr.max_taps), bool(align_corners), False,
                        int(hdr.scatter_off), int(hdr.scatter_ksize), int(hdr.scatter_max), int(hdr.span64p1), int(hdr.span4p1), int(hdr.gather_off))
@@ -171,8 +159,16 @@ def get_table_pair(filter_id: int, kind: int, in_h: int, out_h: int, in_w: int, 
     if th is None and tw is None and kh != kw:
         L = _lib.load()
         with torch.cuda.device(device):
-            bh, k_h = _launch_build(filter_id, kind, in_h, out_h, align_corners, scale_h, device)
-            bw, k_w = _launch_build(filter_id, kind, in_w, out_w, align_corners, scale_w, device)
+            k_h = L.aa_table_ksize(filter_id, kind, in_h, out_h, int(align_corners), float(scale_h or 0.0))
+            _lib.check(k_h, "aa_table_ksize")
+            k_w = L.aa_table_ksize(filter_id, kind, in_w, out_w, int(align_corners), float(scale_w or 0.0))
+            _lib.check(k_w, "aa_table_ksize")
+            nb_h = L.aa_table_build_bytes(filter_id, kind, in_h, out_h, int(align_corners), float(scale_h or 0.0))
+            nb_w = L.aa_table_build_bytes(filter_id, kind, in_w, out_w, int(align_corners), float(scale_w or 0.0))
+            bh = torch.empty(nb_h, dtype=torch.uint8, device=device)
+            bw = torch.empty(nb_w, dtype=torch.uint8, device=device)
+            _lib.check(L.aa_table_build2(filter_id, kind, int(align_corners), in_h, out_h, float(scale_h or 0.0), ctypes.c_void_p(bh.data_ptr()), nb_h,
+                                         in_w, out_w, float(scale_w or 0.0), ctypes.c_void_p(bw.data_ptr()), nb_w, _stream_ptr(device)), "aa_table_build2")
             hh, hw = _lib.TableHeader(), _lib.TableHeader()
             _lib.check(L.aa_table_query2(ctypes.c_void_p(bh.data_ptr()), ctypes.c_void_p(bw.data_ptr()), ctypes.byref(hh), ctypes.byref(hw),
                                          _stream_ptr(device)), "aa_table_query2")
